@@ -818,6 +818,14 @@ static double plane_dihedral(const OrcPlane *a, const OrcPlane *b) {
     return fold_deg(acos(dot / (norm3(a->n) * norm3(b->n))));
 }
 
+/* residues.rs:31-75 exposed for the plane-identity tests (residues.rs:306-332): out = {|c2-c1|, dihedral, angle(p1, c2)} */
+void orc_plane_metrics(const double c1[3], const double n1[3], const double c2[3], const double n2[3], double out[3]) {
+    OrcPlane a, b;
+    memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
+    memcpy(a.c, c1, sizeof a.c); memcpy(a.n, n1, sizeof a.n); memcpy(b.c, c2, sizeof b.c); memcpy(b.n, n2, sizeof b.n);
+    out[0] = plane_point_dist(&a, b.c); out[1] = plane_dihedral(&a, &b); out[2] = plane_point_angle(&a, b.c);
+}
+
 /* complex.rs:442-514 (quirk: for every model serial, ALL chains of ALL models are visited; a later model's
  * residue with the same id overwrites the earlier plane).  One entry per (model serial, conformer key). */
 typedef struct { OrcPlane *p; int32_t n, cap; } PlaneVec;

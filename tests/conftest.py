@@ -1,0 +1,26 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+DATA = ROOT / "tests" / "data"
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ubq_path():
+    return str(DATA / "1ubq.pdb")
+
+
+@pytest.fixture(scope="session")
+def bft_path():
+    return str(DATA / "6bft.pdb")
