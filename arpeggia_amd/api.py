@@ -1,0 +1,346 @@
+"""Python surface of the MI355X-native contact engine.
+
+Mirrors the reference's PyO3 module for the one path this repo replaces:
+`arpeggia.contacts(input_file, groups="/", vdw_comp=0.1, dist_cutoff=6.5, ignore_zero_occupancy=False, num_threads=1)`
+(reference: src/python.rs:31-56, stubs python/arpeggia/arpeggia.pyi:7-33) plus the Rust-level pieces it is made of
+(`load_model` utils.rs:51, `parse_groups` utils.rs:71, `get_contacts` contacts/mod.rs:61).
+
+Everything numeric happens in libarpeggia_amd.so on a gfx950 device; this file only marshals pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+PAIR_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("dist", "<f4"), ("kind", "<u4")])
+
+TABLE_COLUMNS = [  # mod.rs:140-181 + 209-211, in the reference's order with its dtypes
+    ("model", "u4"), ("interaction", "str"), ("distance", "f4"),
+    ("from_chain", "str"), ("from_resn", "str"), ("from_resi", "i4"), ("from_insertion", "str"), ("from_altloc", "str"),
+    ("from_atomn", "str"), ("from_atomi", "i4"),
+    ("to_chain", "str"), ("to_resn", "str"), ("to_resi", "i4"), ("to_insertion", "str"), ("to_altloc", "str"),
+    ("to_atomn", "str"), ("to_atomi", "i4"),
+    ("sc_centroid_dist", "f4"), ("sc_dihedral", "f4"), ("sc_centroid_angle", "f4"),
+]
+
+
+class ArpeggiaError(RuntimeError):
+    """Raised where the reference panics (pyo3_runtime.PanicException) or a HIP call fails."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+def _check(status: int):
+    if status != _lib.ARP_OK:
+        msg = lib.arp_last_error().decode() or lib.arp_strerror(status).decode()
+        raise ArpeggiaError(status, msg)
+
+
+def device_count() -> int:
+    return int(lib.arp_device_count())
+
+
+def default_params(vdw_comp: float = 0.1, dist_cutoff: float = 6.5) -> _lib.arp_params:
+    p = _lib.arp_params()
+    lib.arp_default_params(C.byref(p))
+    p.vdw_comp = vdw_comp
+    p.dist_cutoff = dist_cutoff
+    return p
+
+
+def parse_groups(all_chains, groups: str):
+    """utils.rs:71-115 on a throw-away structure with one atom per chain (keeps ONE implementation, in C++)."""
+    chains = sorted(set(all_chains))
+    n = len(chains)
+    rec = {
+        "x": np.zeros(n), "y": np.zeros(n), "z": np.arange(n, dtype=np.float64) * 100.0,
+        "serial": np.arange(1, n + 1, dtype=np.int32), "resi": np.ones(n, dtype=np.int32),
+        "name": np.array([b"CA"] * n, dtype="S8"), "resn": np.array([b"GLY"] * n, dtype="S8"),
+        "chain": np.array([c.encode() for c in chains], dtype="S8"), "element": np.array([b"C"] * n, dtype="S4"),
+    }
+    s = Structure.from_records(rec)
+    soa = s.soa(groups)
+    lig = {chains[k] for k in range(n) if soa["attr"][k] & _lib.ATTR["LIGAND"]}
+    recp = {chains[k] for k in range(n) if soa["attr"][k] & _lib.ATTR["RECEPTOR"]}
+    return lig, recp
+
+
+def _np_from(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    dt = np.dtype(dtype)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+
+class Structure:
+    """A parsed, filtered model: what `load_model` (utils.rs:51-63) returns in the reference."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.arp_structure_free(self._h)
+            self._h = None
+
+    @classmethod
+    def load(cls, path, ignore_zero_occupancy: bool = False) -> "Structure":
+        h = C.c_void_p()
+        _check(lib.arp_structure_load(os.fsencode(str(path)), int(ignore_zero_occupancy), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_records(cls, rec: dict, hierarchy: bool = False) -> "Structure":
+        """rec: columns x,y,z f64; serial,resi i32; name,resn,chain S8; element S4; optional occupancy f64, model_serial i32,
+        altloc/icode S4; with hierarchy=True also res_ord,res_id u32 (synthetic inputs)."""
+        n = len(rec["x"])
+        keep = {}
+
+        def col(name, dtype, required=True):
+            if name not in rec or rec[name] is None:
+                if required:
+                    raise KeyError(name)
+                return None
+            a = np.ascontiguousarray(rec[name], dtype=dtype)
+            assert len(a) == n, name
+            keep[name] = a
+            return a.ctypes.data
+
+        r = _lib.arp_records()
+        r.n = n
+        r.x, r.y, r.z = col("x", "<f8"), col("y", "<f8"), col("z", "<f8")
+        r.occupancy = col("occupancy", "<f8", False)
+        r.serial, r.resi = col("serial", "<i4"), col("resi", "<i4")
+        r.model_serial = col("model_serial", "<i4", False)
+        r.name, r.resn, r.chain = col("name", "S8"), col("resn", "S8"), col("chain", "S8")
+        r.altloc, r.icode = col("altloc", "S4", False), col("icode", "S4", False)
+        r.element = col("element", "S4")
+        r.res_ord, r.res_id = col("res_ord", "<u4", hierarchy), col("res_id", "<u4", hierarchy)
+        h = C.c_void_p()
+        _check(lib.arp_structure_from_records(C.byref(r), int(hierarchy), C.byref(h)))
+        return cls(h)
+
+    @property
+    def n_atoms(self) -> int:
+        return int(lib.arp_structure_n_atoms(self._h))
+
+    def strings(self, column: str) -> np.ndarray:
+        w = C.c_int32()
+        p = lib.arp_structure_strings(self._h, column.encode(), C.byref(w))
+        if not p:
+            raise KeyError(column)
+        return _np_from(p, self.n_atoms, f"S{w.value}")
+
+    def ints(self, column: str) -> np.ndarray:
+        p = lib.arp_structure_ints(self._h, column.encode())
+        if not p:
+            raise KeyError(column)
+        return _np_from(p, self.n_atoms, "<i4")
+
+    def view(self, groups: str = "/") -> _lib.arp_atoms:
+        """Borrowed host SoA view (valid until the next view()/soa() call on this structure)."""
+        v = _lib.arp_atoms()
+        _check(lib.arp_structure_atoms(self._h, groups.encode(), C.byref(v)))
+        return v
+
+    def soa(self, groups: str = "/") -> dict:
+        """Copy of the SoA columns the GPU path consumes (include/arpeggia_amd.h: arp_atoms)."""
+        v = self.view(groups)
+        n, nr = int(v.n), int(v.n_res)
+        out = {
+            "x": _np_from(v.x, n, "<f8"), "y": _np_from(v.y, n, "<f8"), "z": _np_from(v.z, n, "<f8"),
+            "attr": _np_from(v.attr, n, "<u4"), "res_ord": _np_from(v.res_ord, n, "<u4"),
+            "chain_rank": _np_from(v.chain_rank, n, "<u2"), "model": _np_from(v.model, n, "<u2"),
+            "res_id": _np_from(v.res_id, n, "<u4"),
+            "res_h_ptr": _np_from(v.res_h_ptr, nr + 1 if nr else 0, "<u4"),
+            "res_cb": _np_from(v.res_cb, nr, "<u4"), "res_sg": _np_from(v.res_sg, nr, "<u4"),
+        }
+        nh = int(out["res_h_ptr"][-1]) if nr else 0
+        out["res_h_idx"] = _np_from(v.res_h_idx, nh, "<u4")
+        return out
+
+
+def atoms_from_arrays(soa: dict, location: int = _lib.ARP_MEM_HOST, keep: list | None = None) -> _lib.arp_atoms:
+    """Build an arp_atoms from numpy arrays (host) or from objects with .data_ptr() (device tensors)."""
+    v = _lib.arp_atoms()
+
+    def ptr(name, dtype):
+        a = soa.get(name)
+        if a is None:
+            return None
+        if hasattr(a, "data_ptr"):
+            if keep is not None:
+                keep.append(a)
+            return a.data_ptr() if a.numel() else None
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if keep is not None:
+            keep.append(a)
+        return a.ctypes.data if a.size else None
+
+    x = soa["x"]
+    v.n = int(x.numel() if hasattr(x, "numel") else len(x))
+    v.x, v.y, v.z = ptr("x", "<f8"), ptr("y", "<f8"), ptr("z", "<f8")
+    v.attr, v.res_ord = ptr("attr", "<u4"), ptr("res_ord", "<u4")
+    v.chain_rank, v.model = ptr("chain_rank", "<u2"), ptr("model", "<u2")
+    rcb = soa.get("res_cb")
+    v.n_res = int((rcb.numel() if hasattr(rcb, "numel") else len(rcb))) if rcb is not None else 0
+    if v.n_res:
+        v.res_id = ptr("res_id", "<u4")
+        v.res_h_ptr, v.res_h_idx = ptr("res_h_ptr", "<u4"), ptr("res_h_idx", "<u4")
+        v.res_cb, v.res_sg = ptr("res_cb", "<u4"), ptr("res_sg", "<u4")
+    v.location = location
+    return v
+
+
+class Context:
+    """One engine context = one device + one stream + a reusable workspace (arp_context)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        _check(lib.arp_context_create(device, C.byref(h)))
+        self._h = h
+        self._keep = []
+        if stream is not None:
+            self.set_stream(stream)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.arp_context_destroy(self._h)
+            self._h = None
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib.arp_context_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        _check(lib.arp_context_synchronize(self._h))
+
+    def atomic_contacts(self, atoms, params: _lib.arp_params | None = None) -> np.ndarray:
+        """Synchronous hot path (complex.rs:189-299).  atoms: Structure view / arp_atoms / dict of numpy arrays."""
+        keep = []
+        if isinstance(atoms, dict):
+            atoms = atoms_from_arrays(atoms, keep=keep)
+        params = params or default_params()
+        out = _lib.arp_pairs()
+        _check(lib.arp_contacts_atomic(self._h, C.byref(atoms), C.byref(params), _lib.ARP_MEM_HOST, C.byref(out)))
+        try:
+            return _np_from(out.data, int(out.n), PAIR_DTYPE)
+        finally:
+            lib.arp_pairs_free(C.byref(out))
+
+    def enqueue(self, atoms: _lib.arp_atoms, params: _lib.arp_params, out_ptr: int, capacity: int):
+        """Asynchronous, allocation-free form on device-resident data (arp_contacts_atomic_enqueue)."""
+        _check(lib.arp_contacts_atomic_enqueue(self._h, C.byref(atoms), C.byref(params), C.c_void_p(out_ptr), capacity))
+
+    def result(self) -> int:
+        n = C.c_uint64()
+        st = lib.arp_contacts_atomic_result(self._h, C.byref(n))
+        if st == _lib.ARP_ERR_CAPACITY:
+            raise ArpeggiaError(st, f"pair buffer too small: {n.value} pairs needed")
+        _check(st)
+        return int(n.value)
+
+    def profile(self, on: bool):
+        _check(lib.arp_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> dict:
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        k = lib.arp_profile_read(self._h, names, ms, 32)
+        return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+    def get_contacts(self, structure: Structure, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5) -> dict:
+        """`arpeggia::get_contacts` (mod.rs:61-137): the sorted 20-column table as a dict of numpy columns."""
+        t = C.c_void_p()
+        _check(lib.arp_get_contacts(self._h, structure._h, groups.encode(), vdw_comp, dist_cutoff, C.byref(t)))
+        try:
+            n = int(lib.arp_table_rows(t))
+            cols = {}
+
+            def col(name, dtype=None):
+                w = C.c_int32()
+                p = lib.arp_table_column(t, name.encode(), C.byref(w))
+                if not p and n:
+                    raise KeyError(name)
+                return _np_from(p, n, dtype or f"S{w.value}")
+
+            for name, kind in TABLE_COLUMNS:
+                if name == "interaction":
+                    cols[name] = col(name, "<i4")
+                elif kind == "str":
+                    cols[name] = col(name)
+                else:
+                    cols[name] = col(name, "<" + kind)
+            cols["sc_valid"] = col("sc_valid", "u1").astype(bool)
+            cols["from_atom"] = col("from_atom", "<i4")
+            cols["to_atom"] = col("to_atom", "<i4")
+            return cols
+        finally:
+            lib.arp_table_free(t)
+
+
+_default_ctx: dict = {}
+
+
+def _context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def load_model(input_file, ignore_zero_occupancy: bool = False) -> Structure:
+    """utils.rs:51-63."""
+    return Structure.load(input_file, ignore_zero_occupancy)
+
+
+def get_contacts(structure: Structure, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5, device: int = 0):
+    """`arpeggia::get_contacts(&pdb, groups, vdw_comp, dist_cutoff) -> DataFrame` (mod.rs:61)."""
+    return _to_frame(_context(device).get_contacts(structure, groups, vdw_comp, dist_cutoff))
+
+
+def _to_frame(cols: dict):
+    import pyarrow as pa
+
+    names = np.array(_lib.INTERACTIONS)
+    arrays, fields = [], []
+    valid = cols["sc_valid"]
+    for name, kind in TABLE_COLUMNS:
+        v = cols[name]
+        if name == "interaction":
+            arr = pa.array(names[v], type=pa.string()) if len(v) else pa.array([], type=pa.string())
+        elif kind == "str":
+            arr = pa.array(np.char.decode(v, "ascii") if len(v) else [], type=pa.string())
+        elif name.startswith("sc_"):
+            arr = pa.array(v, type=pa.float32(), mask=~valid)  # null where either residue has no side-chain plane
+        else:
+            arr = pa.array(v, type={"u4": pa.uint32(), "i4": pa.int32(), "f4": pa.float32()}[kind])
+        arrays.append(arr)
+        fields.append(name)
+    table = pa.table(arrays, names=fields)
+    try:  # the reference returns a polars.DataFrame (python.rs:55); same Arrow buffers when polars is installed
+        import polars as pl
+
+        return pl.from_arrow(table)
+    except ImportError:
+        return table
+
+
+def contacts(input_file: str, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5,
+             ignore_zero_occupancy: bool = False, num_threads: int = 1):
+    """Drop-in for `arpeggia.contacts` (src/python.rs:31-56): same keywords and defaults, 20-column table.
+
+    Returns a polars.DataFrame when polars is importable, else the identical pyarrow.Table.  `num_threads` is accepted
+    for signature compatibility (the reference sizes a rayon pool with it, utils.rs:8-30); the search and classification
+    run on the GPU regardless.
+    """
+    del num_threads
+    s = Structure.load(input_file, ignore_zero_occupancy)
+    return get_contacts(s, groups, vdw_comp, dist_cutoff)

@@ -1,0 +1,59 @@
+"""Build libarpeggia_amd.so (HIP kernels + C++ host engine) in-tree for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only authoring container.  The built .so is
+git-ignored but travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libarpeggia_amd.so"
+SOURCES = ["kernels.hip", "engine.cpp", "structure.cpp", "table.cpp"]
+HEADERS = ["arp_internal.h", "host_common.h", "../../include/arpeggia_amd.h"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    build_dir = PKG / "build"
+    build_dir.mkdir(exist_ok=True)
+    cc = hipcc()
+    for src in SOURCES:
+        obj = build_dir / (src.replace(".", "_") + ".o")
+        cmd = [cc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        if src.endswith(".cpp"):
+            cmd[1:1] = ["-x", "hip"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(str(obj))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB), "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

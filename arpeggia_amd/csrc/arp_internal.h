@@ -1,0 +1,100 @@
+// Internal declarations shared by the HIP kernels (kernels.hip) and the host engine (engine.cpp).
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#include "../../include/arpeggia_amd.h"
+
+namespace arp {
+
+// Decision constants in SQUARED-distance space.  The reference compares d = sqrt(s) (correctly rounded f64)
+// against thresholds T with `<` (vdw.rs:33-41) or `<=` (everything else).  Because rn(sqrt(.)) is monotone,
+// {s : sqrt(s) < T} = {s : s < lt(T)} with lt(T) = min{s : sqrt(s) >= T}; likewise d <= T  <=>  s < le(T).
+// The host computes lt/le exactly (engine.cpp: bound_lt / bound_le), so the device never needs a sqrt to decide.
+struct DevParams {
+    double r2;            // dist_cutoff^2, inclusive candidate test d^2 <= r2 (rstar locate_within_distance)
+    double s_ion;         // le(4.0)   ionic.rs:5, hbond.rs:7
+    double s_polar;       // le(3.5)   hbond.rs:8
+    double s_hphob;       // le(4.5)   hydrophobic.rs:5
+    double s_clash[256];  // lt(cov[a]+cov[b] - c)   vdw.rs:33
+    double s_cov[256];    // lt(cov[a]+cov[b] + c)   vdw.rs:34
+    double s_vdw[256];    // lt(vdw[a]+vdw[b] + c)   vdw.rs:41
+    double s_hacc[16];    // le(h_vdw + vdw[acceptor] + c)   hbond.rs:54,98
+    float r2f;            // prefilter threshold in f32 (r2 + margin), set by the grid setup kernel
+    uint32_t pad;
+};
+
+// Uniform grid, written by the device-side setup kernel (no host round trip).
+struct GridParams {
+    double ox, oy, oz;    // origin = min corner of the heavy atoms
+    double inv_edge;      // 1 / cell edge, edge >= dist_cutoff * (1 + 1e-6)
+    uint32_t nx, ny, nz;  // cells per axis for ONE model
+    uint32_t nzt;         // total z layers = n_models * (nz + 1): each model gets its own slab + an empty separator
+    uint32_t ncells;      // nx * ny * nzt
+    uint32_t n_heavy;     // atoms in the grid (non-H)
+    uint32_t bad;         // non-finite coordinate seen
+    float prefilter_margin;
+};
+
+struct Bounds {           // order-preserving u64 encodings of f64 min/max, reduced with atomics
+    unsigned long long mn[3], mx[3];
+    uint32_t n_models;    // max model ordinal + 1
+    uint32_t bad;
+};
+
+// Device view of the caller's SoA (all device pointers).
+struct DevAtoms {
+    uint32_t n;
+    const double *x, *y, *z;
+    const uint32_t *attr, *res_ord;
+    const uint16_t *chain_rank, *model;
+    const uint32_t *res_id, *res_h_ptr, *res_h_idx, *res_cb, *res_sg;
+    uint32_t n_res;
+};
+
+// Cell-sorted copy of the heavy atoms (slot order: x-major cells, atoms of a cell in ascending input index).
+struct Sorted {
+    float4 *rec;          // {x-ox, y-oy, z-oz as f32, bits(original atom index)}  -- prefilter operand, 16 B
+    double *x, *y, *z;    // exact coordinates for the f64 decision
+    uint4 *meta;          // {attr, res_ord, chain_rank | model << 16, original index}
+};
+
+struct Workspace {
+    Bounds *bounds;
+    GridParams *grid;
+    DevParams *params;
+    uint32_t *cell_of_atom;   // n
+    uint32_t *cell_count;     // ncells_cap + 1
+    uint32_t *cell_start;     // ncells_cap + 1
+    uint32_t *cell_fill;      // ncells_cap
+    uint32_t *perm;           // n: slot -> atom (unordered inside a cell)
+    uint32_t *slot_cell;      // n
+    Sorted sorted;
+    uint32_t *task_count;     // ncells_cap + 1: candidate pairs per home cell
+    unsigned long long *task_base;  // ncells_cap + 1
+    uint32_t *scan_tmp;       // block sums (1024 + 1)
+    unsigned long long *scan_tmp64;
+    unsigned long long *result;  // [0] = total pairs, [1] = overflow flag
+    uint32_t ncells_cap;
+    uint32_t n_cap;
+};
+
+// Launch wrappers (kernels.hip).  All asynchronous on `st`.
+struct Profiler;
+void launch_pipeline(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
+                     bool fill, Profiler *prof, double cutoff);
+void launch_fill_only(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
+                      Profiler *prof);
+
+struct Profiler {
+    static constexpr int kMax = 32;
+    bool enabled = false;
+    int n = 0;
+    const char *names[kMax];
+    hipEvent_t ev0[kMax], ev1[kMax];
+    bool created = false;
+    void begin(const char *name, hipStream_t st);
+    void end(hipStream_t st);
+};
+
+}  // namespace arp

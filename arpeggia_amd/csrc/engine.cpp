@@ -1,0 +1,453 @@
+// Host engine: context / workspace management and the C-ABI entry points of the atomic-contact hot path
+// (include/arpeggia_amd.h).  Compiled with hipcc for the HIP runtime API; all device code lives in kernels.hip.
+// There is NO CPU compute path here: without a gfx950 device every compute call returns ARP_ERR_NO_DEVICE.
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "arp_internal.h"
+#include "host_common.h"
+
+namespace arp {
+
+thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_error("HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+            return (e_ == hipErrorOutOfMemory) ? ARP_ERR_OOM : ARP_ERR_HIP;                        \
+        }                                                                                          \
+    } while (0)
+
+// ---- exact squared-distance decision bounds (see DevParams) ------------------------------------------------
+// min{ s >= 0 : sqrt(s) >= T }  so that  (sqrt(s) < T)  <=>  (s < bound_lt(T)).  Host sqrt is correctly rounded.
+double bound_lt(double T) {
+    if (!(T > 0.0)) return 0.0;  // T <= 0 or NaN: d < T never holds for d >= 0
+    if (std::isinf(T)) return INFINITY;
+    double s = T * T;
+    if (!std::isfinite(s)) s = DBL_MAX;
+    while (s > 0.0 && std::sqrt(s) >= T) s = std::nextafter(s, 0.0);
+    while (std::sqrt(s) < T) s = std::nextafter(s, INFINITY);
+    return s;
+}
+// min{ s >= 0 : sqrt(s) > T }  so that  (sqrt(s) <= T)  <=>  (s < bound_le(T)).
+double bound_le(double T) {
+    if (!(T >= 0.0)) return 0.0;
+    if (std::isinf(T)) return INFINITY;
+    double s = T * T;
+    if (!std::isfinite(s)) s = DBL_MAX;
+    while (s > 0.0 && std::sqrt(s) > T) s = std::nextafter(s, 0.0);
+    while (std::sqrt(s) <= T) s = std::nextafter(s, INFINITY);
+    return s;
+}
+
+void make_dev_params(const arp_params &p, DevParams *d) {
+    memset(d, 0, sizeof *d);
+    const double c = p.vdw_comp;
+    d->r2 = p.dist_cutoff * p.dist_cutoff;  // complex.rs:191
+    d->s_ion = bound_le(4.0);
+    d->s_polar = bound_le(3.5);
+    d->s_hphob = bound_le(4.5);
+    for (int a = 0; a < 16; a++) {
+        for (int b = 0; b < 16; b++) {
+            double sum_cov = p.cov_radius[a] + p.cov_radius[b];  // vdw.rs:27
+            double sum_vdw = p.vdw_radius[a] + p.vdw_radius[b];  // vdw.rs:28
+            d->s_clash[a * 16 + b] = bound_lt(sum_cov - c);
+            d->s_cov[a * 16 + b] = bound_lt(sum_cov + c);
+            d->s_vdw[a * 16 + b] = bound_lt(sum_vdw + c);
+        }
+        d->s_hacc[a] = bound_le(p.h_vdw_radius + p.vdw_radius[a] + c);  // hbond.rs:54
+    }
+    d->r2f = (float)d->r2;
+}
+
+}  // namespace arp
+
+using namespace arp;
+
+// ---- context -------------------------------------------------------------------------------------------------
+struct arp_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    Workspace ws{};
+    std::vector<void *> ws_allocs;
+    // device staging of host inputs
+    struct Staged {
+        void *x = nullptr, *y = nullptr, *z = nullptr, *attr = nullptr, *res_ord = nullptr, *chain_rank = nullptr, *model = nullptr;
+        void *res_id = nullptr, *res_h_ptr = nullptr, *res_h_idx = nullptr, *res_cb = nullptr, *res_sg = nullptr;
+        uint64_t n_cap = 0, nres_cap = 0, nh_cap = 0;
+    } st;
+    DevParams *h_params = nullptr;         // pinned
+    unsigned long long *h_result = nullptr;  // pinned [2]
+    arp_params last_params{};
+    bool have_params = false;
+    uint64_t last_capacity = 0;
+    bool pending = false;
+    Profiler prof;
+};
+
+static arp_status check_device(arp_context *ctx) {
+    if (!ctx) { set_error("null context"); return ARP_ERR_BAD_INPUT; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ARP_OK;
+}
+
+template <typename T>
+static arp_status dev_alloc(arp_context *ctx, T **p, size_t count) {
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    ctx->ws_allocs.push_back(q);
+    *p = (T *)q;
+    return ARP_OK;
+}
+
+static void free_workspace(arp_context *ctx) {
+    for (void *p : ctx->ws_allocs) (void)hipFree(p);
+    ctx->ws_allocs.clear();
+    ctx->ws = Workspace{};
+}
+
+static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
+    Workspace &w = ctx->ws;
+    if (w.n_cap >= n && w.bounds) return ARP_OK;
+    if (n >= 0xFFFFFFF0ull) { set_error("too many atoms for 32-bit indices"); return ARP_ERR_BAD_INPUT; }
+    (void)hipStreamSynchronize(ctx->stream);
+    free_workspace(ctx);
+    uint64_t cap = std::max<uint64_t>(n + n / 8, 1024);
+    uint64_t ccap = std::min<uint64_t>(8 * cap + 65536, 0xFFFFFFF0ull);
+    arp_status s;
+#define A(ptr, cnt) if ((s = dev_alloc(ctx, &(ptr), (cnt))) != ARP_OK) { free_workspace(ctx); return s; }
+    A(w.bounds, 1); A(w.grid, 1); A(w.params, 1);
+    A(w.cell_of_atom, cap); A(w.cell_count, ccap + 1); A(w.cell_start, ccap + 1); A(w.cell_fill, ccap + 1);
+    A(w.perm, cap); A(w.slot_cell, cap);
+    A(w.sorted.rec, cap); A(w.sorted.x, cap); A(w.sorted.y, cap); A(w.sorted.z, cap); A(w.sorted.meta, cap);
+    A(w.task_count, ccap + 1); A(w.task_base, ccap + 1);
+    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 2);
+#undef A
+    w.n_cap = (uint32_t)cap;
+    w.ncells_cap = (uint32_t)ccap;
+    return ARP_OK;
+}
+
+extern "C" arp_status arp_context_create(int32_t device, arp_context **out) {
+    if (!out) { set_error("null out"); return ARP_ERR_BAD_INPUT; }
+    *out = nullptr;
+    int cnt = arp_device_count();
+    if (cnt <= 0) { set_error("no gfx950 (MI355X) device visible; this engine has no CPU fallback"); return ARP_ERR_NO_DEVICE; }
+    if (device < 0 || device >= cnt) { set_error("device %d out of range (0..%d)", device, cnt - 1); return ARP_ERR_NO_DEVICE; }
+    arp_context *ctx = new arp_context();
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_params, sizeof(DevParams), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("HIP error %d (%s) creating the context", (int)e, hipGetErrorString(e));
+        arp_context_destroy(ctx);
+        return ARP_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return ARP_OK;
+}
+
+static void free_staged(arp_context *ctx) {
+    auto &s = ctx->st;
+    void *ps[] = {s.x, s.y, s.z, s.attr, s.res_ord, s.chain_rank, s.model, s.res_id, s.res_h_ptr, s.res_h_idx, s.res_cb, s.res_sg};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    s = arp_context::Staged{};
+}
+
+extern "C" void arp_context_destroy(arp_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_workspace(ctx);
+    free_staged(ctx);
+    if (ctx->h_params) (void)hipHostFree(ctx->h_params);
+    if (ctx->h_result) (void)hipHostFree(ctx->h_result);
+    if (ctx->prof.created) for (int k = 0; k < Profiler::kMax; k++) { (void)hipEventDestroy(ctx->prof.ev0[k]); (void)hipEventDestroy(ctx->prof.ev1[k]); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" arp_status arp_context_set_stream(arp_context *ctx, void *hip_stream) {
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ARP_OK;
+}
+
+extern "C" arp_status arp_context_synchronize(arp_context *ctx) {
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ARP_OK;
+}
+
+// ---- input handling -------------------------------------------------------------------------------------------
+static arp_status validate(const arp_atoms *a, const arp_params *p) {
+    if (!a || !p) { set_error("null atoms/params"); return ARP_ERR_BAD_INPUT; }
+    if (a->n >= 0xFFFFFFF0ull) { set_error("too many atoms"); return ARP_ERR_BAD_INPUT; }
+    if (a->n && (!a->x || !a->y || !a->z || !a->attr || !a->res_ord || !a->chain_rank || !a->model)) { set_error("null atom array"); return ARP_ERR_BAD_INPUT; }
+    if (a->n_res && (!a->res_id || !a->res_h_ptr || !a->res_cb || !a->res_sg)) { set_error("null residue table"); return ARP_ERR_BAD_INPUT; }
+    if (a->n_res >= 0xFFFFFFF0ull) { set_error("too many residues"); return ARP_ERR_BAD_INPUT; }
+    if (a->location != ARP_MEM_HOST && a->location != ARP_MEM_DEVICE) { set_error("bad location"); return ARP_ERR_BAD_INPUT; }
+    if (std::isnan(p->dist_cutoff) || std::isnan(p->vdw_comp)) { set_error("NaN parameter"); return ARP_ERR_BAD_INPUT; }
+    return ARP_OK;
+}
+
+template <typename T>
+static arp_status stage(void **dst, const T *src, uint64_t count, hipStream_t st) {
+    if (!count) return ARP_OK;
+    HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+    return ARP_OK;
+}
+
+static arp_status stage_inputs(arp_context *ctx, const arp_atoms *a, DevAtoms *d) {
+    d->n = (uint32_t)a->n;
+    d->n_res = (uint32_t)a->n_res;
+    if (a->location == ARP_MEM_DEVICE) {
+        d->x = a->x; d->y = a->y; d->z = a->z; d->attr = a->attr; d->res_ord = a->res_ord; d->chain_rank = a->chain_rank; d->model = a->model;
+        d->res_id = a->res_id; d->res_h_ptr = a->res_h_ptr; d->res_h_idx = a->res_h_idx; d->res_cb = a->res_cb; d->res_sg = a->res_sg;
+        return ARP_OK;
+    }
+    auto &s = ctx->st;
+    uint64_t nh = 0;
+    if (a->n_res) nh = a->res_h_ptr[a->n_res];
+    if (nh && !a->res_h_idx) { set_error("null res_h_idx"); return ARP_ERR_BAD_INPUT; }
+    if (s.n_cap < a->n || s.nres_cap < a->n_res || s.nh_cap < nh) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_staged(ctx);
+        uint64_t nc = std::max<uint64_t>(a->n + a->n / 8, 1024), rc = std::max<uint64_t>(a->n_res + a->n_res / 8, 16), hc = std::max<uint64_t>(nh + nh / 8, 16);
+        HIP_TRY(hipMalloc(&s.x, nc * 8)); HIP_TRY(hipMalloc(&s.y, nc * 8)); HIP_TRY(hipMalloc(&s.z, nc * 8));
+        HIP_TRY(hipMalloc(&s.attr, nc * 4)); HIP_TRY(hipMalloc(&s.res_ord, nc * 4));
+        HIP_TRY(hipMalloc(&s.chain_rank, nc * 2)); HIP_TRY(hipMalloc(&s.model, nc * 2));
+        HIP_TRY(hipMalloc(&s.res_id, nc * 4));
+        HIP_TRY(hipMalloc(&s.res_h_ptr, (rc + 1) * 4)); HIP_TRY(hipMalloc(&s.res_cb, rc * 4)); HIP_TRY(hipMalloc(&s.res_sg, rc * 4));
+        HIP_TRY(hipMalloc(&s.res_h_idx, hc * 4));
+        s.n_cap = nc; s.nres_cap = rc; s.nh_cap = hc;
+    }
+    hipStream_t st = ctx->stream;
+    arp_status r;
+    if ((r = stage(&s.x, a->x, a->n, st)) || (r = stage(&s.y, a->y, a->n, st)) || (r = stage(&s.z, a->z, a->n, st)) ||
+        (r = stage(&s.attr, a->attr, a->n, st)) || (r = stage(&s.res_ord, a->res_ord, a->n, st)) ||
+        (r = stage(&s.chain_rank, a->chain_rank, a->n, st)) || (r = stage(&s.model, a->model, a->n, st)))
+        return r;
+    if (a->n_res) {
+        if ((r = stage(&s.res_id, a->res_id, a->n, st)) || (r = stage(&s.res_h_ptr, a->res_h_ptr, a->n_res + 1, st)) ||
+            (r = stage(&s.res_cb, a->res_cb, a->n_res, st)) || (r = stage(&s.res_sg, a->res_sg, a->n_res, st)) ||
+            (r = stage(&s.res_h_idx, a->res_h_idx, nh, st)))
+            return r;
+    }
+    d->x = (const double *)s.x; d->y = (const double *)s.y; d->z = (const double *)s.z;
+    d->attr = (const uint32_t *)s.attr; d->res_ord = (const uint32_t *)s.res_ord;
+    d->chain_rank = (const uint16_t *)s.chain_rank; d->model = (const uint16_t *)s.model;
+    d->res_id = (const uint32_t *)s.res_id; d->res_h_ptr = (const uint32_t *)s.res_h_ptr; d->res_h_idx = (const uint32_t *)s.res_h_idx;
+    d->res_cb = (const uint32_t *)s.res_cb; d->res_sg = (const uint32_t *)s.res_sg;
+    return ARP_OK;
+}
+
+static arp_status upload_params(arp_context *ctx, const arp_params *p) {
+    if (!ctx->have_params || memcmp(&ctx->last_params, p, sizeof *p) != 0) {
+        // the pinned buffer may still be in flight from the previous call
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        make_dev_params(*p, ctx->h_params);
+        ctx->last_params = *p;
+        ctx->have_params = true;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->ws.params, ctx->h_params, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+    return ARP_OK;
+}
+
+static arp_status flags_to_status(unsigned long long flags) {
+    if (flags & 4ull) { set_error("non-finite atom coordinate"); return ARP_ERR_BAD_INPUT; }
+    if (flags & 2ull) { set_error("CYS SG..SG covalent pair whose residue has no CB (the reference panics in is_disulfide, vdw.rs:58)"); return ARP_ERR_BAD_INPUT; }
+    return ARP_OK;
+}
+
+// ---- the hot path ----------------------------------------------------------------------------------------------
+extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, arp_pair *out,
+                                                  uint64_t capacity) {
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    if ((s = validate(atoms, params)) != ARP_OK) return s;
+    if (atoms->location != ARP_MEM_DEVICE) { set_error("arp_contacts_atomic_enqueue needs device-resident inputs"); return ARP_ERR_BAD_INPUT; }
+    if (!out && capacity) { set_error("null output buffer"); return ARP_ERR_BAD_INPUT; }
+    if ((s = ensure_workspace(ctx, atoms->n)) != ARP_OK) return s;
+    DevAtoms d{};
+    if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
+    if ((s = upload_params(ctx, params)) != ARP_OK) return s;
+    launch_pipeline(d, ctx->ws, out, capacity, ctx->stream, /*fill=*/true, ctx->prof.enabled ? &ctx->prof : nullptr, params->dist_cutoff);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->last_capacity = capacity;
+    ctx->pending = true;
+    return ARP_OK;
+}
+
+extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs) {
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    if (!ctx->pending) { set_error("no enqueued call"); return ARP_ERR_BAD_INPUT; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->pending = false;
+    if (n_pairs) *n_pairs = ctx->h_result[0];
+    if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
+    if (ctx->h_result[0] > ctx->last_capacity) {
+        set_error("pair buffer too small: %llu pairs needed, capacity %llu", ctx->h_result[0], (unsigned long long)ctx->last_capacity);
+        return ARP_ERR_CAPACITY;
+    }
+    return ARP_OK;
+}
+
+extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location,
+                                          arp_pairs *out) {
+    if (!out) { set_error("null out"); return ARP_ERR_BAD_INPUT; }
+    out->n = 0; out->data = nullptr; out->location = out_location;
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    if ((s = validate(atoms, params)) != ARP_OK) return s;
+    if (out_location != ARP_MEM_HOST && out_location != ARP_MEM_DEVICE) { set_error("bad out_location"); return ARP_ERR_BAD_INPUT; }
+    if ((s = ensure_workspace(ctx, atoms->n)) != ARP_OK) return s;
+    DevAtoms d{};
+    if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
+    if ((s = upload_params(ctx, params)) != ARP_OK) return s;
+    Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
+    // count pass -> exact output size -> fill pass
+    launch_pipeline(d, ctx->ws, nullptr, 0, ctx->stream, /*fill=*/false, prof, params->dist_cutoff);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
+    const unsigned long long total = ctx->h_result[0];
+    if (total == 0) return ARP_OK;
+    arp_pair *dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
+    launch_fill_only(d, ctx->ws, dev, total, ctx->stream, prof);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(dev); set_error("HIP error %d (%s) in the fill pass", (int)e, hipGetErrorString(e)); return ARP_ERR_HIP; }
+    if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) { (void)hipFree(dev); return s; }
+    if (out_location == ARP_MEM_DEVICE) {
+        out->data = dev; out->n = total;
+        return ARP_OK;
+    }
+    arp_pair *host = (arp_pair *)malloc(total * sizeof(arp_pair));
+    if (!host) { (void)hipFree(dev); set_error("out of host memory"); return ARP_ERR_OOM; }
+    e = hipMemcpy(host, dev, total * sizeof(arp_pair), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) { free(host); set_error("HIP error %d copying pairs to the host", (int)e); return ARP_ERR_HIP; }
+    out->data = host; out->n = total;
+    return ARP_OK;
+}
+
+extern "C" void arp_pairs_free(arp_pairs *pairs) {
+    if (!pairs || !pairs->data) return;
+    if (pairs->location == ARP_MEM_DEVICE) (void)hipFree(pairs->data);
+    else free(pairs->data);
+    pairs->data = nullptr; pairs->n = 0;
+}
+
+// Independent structures, one host thread + one context (stream) per device, longest-processing-time-first deal.
+extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms, int32_t n_structures,
+                                                const arp_params *params, arp_pairs *outs) {
+    if (!ctxs || n_ctx <= 0 || !atoms || n_structures < 0 || !outs || !params) { set_error("bad batch arguments"); return ARP_ERR_BAD_INPUT; }
+    std::vector<int32_t> order(n_structures);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return atoms[a]->n > atoms[b]->n; });
+    std::vector<std::vector<int32_t>> queue(n_ctx);
+    std::vector<uint64_t> load(n_ctx, 0);
+    for (int32_t k : order) {
+        int best = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        queue[best].push_back(k);
+        load[best] += atoms[k]->n + 1;
+    }
+    std::vector<arp_status> st(n_ctx, ARP_OK);
+    std::vector<std::string> msg(n_ctx);
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_ctx; d++)
+        th.emplace_back([&, d]() {
+            for (int32_t k : queue[d]) {
+                arp_status s = arp_contacts_atomic(ctxs[d], atoms[k], params, ARP_MEM_HOST, &outs[k]);
+                if (s != ARP_OK) { st[d] = s; msg[d] = arp_last_error(); return; }
+            }
+        });
+    for (auto &t : th) t.join();
+    for (int d = 0; d < n_ctx; d++)
+        if (st[d] != ARP_OK) { set_error("%s", msg[d].c_str()); return st[d]; }
+    return ARP_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------------------
+extern "C" arp_status arp_profile_enable(arp_context *ctx, int32_t on) {
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    ctx->prof.enabled = on != 0;
+    ctx->prof.n = 0;
+    return ARP_OK;
+}
+extern "C" int32_t arp_profile_read(arp_context *ctx, const char **names, float *ms, int32_t cap) {
+    if (check_device(ctx) != ARP_OK) return 0;
+    (void)hipStreamSynchronize(ctx->stream);
+    int n = std::min<int>(ctx->prof.n, cap);
+    for (int k = 0; k < n; k++) {
+        names[k] = ctx->prof.names[k];
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, ctx->prof.ev0[k], ctx->prof.ev1[k]);
+        ms[k] = t;
+    }
+    return n;
+}
+
+// ---- library-level -----------------------------------------------------------------------------------------------
+extern "C" int32_t arp_api_version(void) { return ARP_API_VERSION; }
+extern "C" const char *arp_last_error(void) { return g_err; }
+extern "C" const char *arp_strerror(arp_status s) {
+    switch (s) {
+        case ARP_OK: return "ok";
+        case ARP_ERR_BAD_GROUPS: return "Invalid chain groups format! Use '/' for all-to-all comparisons.";
+        case ARP_ERR_EMPTY_GROUPS: return "Empty chain groups!";
+        case ARP_ERR_NO_RINGS: return "Error building ring positions";
+        case ARP_ERR_BAD_INPUT: return "bad input";
+        case ARP_ERR_HIP: return "HIP runtime error";
+        case ARP_ERR_OOM: return "out of memory";
+        case ARP_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+        case ARP_ERR_IO: return "I/O error";
+        case ARP_ERR_CAPACITY: return "pair buffer too small";
+        default: return "unknown status";
+    }
+}
+extern "C" int32_t arp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) != hipSuccess) continue;
+        if (strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+        else return ok;  // devices are addressed by ordinal: stop at the first foreign one
+    }
+    return ok;
+}
+static const char *k_interactions[ARP_N_INTERACTIONS] = {
+    "StericClash", "CovalentBond", "Disulfide", "VanDerWaalsContact", "IonicBond", "HydrogenBond", "WeakHydrogenBond",
+    "PolarContact", "WeakPolarContact", "IonicRepulsion", "SaltBridge", "PiDisplacedStacking", "PiTStacking",
+    "PiSandwichStacking", "PiParallelInPlaneStacking", "PiTiltedStacking", "PiLStacking", "CationPi", "HydrophobicContact"};
+extern "C" const char *arp_interaction_name(int32_t code) { return (code >= 0 && code < ARP_N_INTERACTIONS) ? k_interactions[code] : "?"; }

@@ -1,0 +1,77 @@
+// Host-side declarations shared by engine.cpp, structure.cpp and table.cpp.
+#pragma once
+#include <array>
+#include <cstdarg>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/arpeggia_amd.h"
+
+namespace arp {
+
+void set_error(const char *fmt, ...);
+
+// Fixed-width, NUL-padded string column (n x W chars), the layout the C ABI hands to numpy / Rust.
+template <int W>
+struct StrCol {
+    std::vector<char> buf;
+    void resize(size_t n) { buf.assign(n * W, 0); }
+    size_t size() const { return buf.size() / W; }
+    const char *at(size_t i) const { return &buf[i * W]; }
+    char *at(size_t i) { return &buf[i * W]; }
+    void set(size_t i, const char *s) {
+        char *d = at(i);
+        int k = 0;
+        for (; k < W - 1 && s[k]; k++) d[k] = s[k];
+        for (; k < W; k++) d[k] = 0;
+    }
+    std::string str(size_t i) const { return std::string(at(i)); }
+};
+
+struct Plane {
+    double c[3], n[3];
+};
+
+struct ChainInfo {
+    uint32_t model_idx;
+    int32_t model_serial;
+    std::string id;
+};
+
+struct ResidueInfo {
+    uint32_t chain;       // index into chains
+    int32_t resi;
+    std::string icode;
+    std::string name;     // Residue::name(): common conformer name
+    uint32_t ord;         // positional index inside the chain (complex.rs:411-440)
+    std::vector<uint32_t> atoms;         // atom indices in hierarchy order (conformer ordinal, then input order)
+    std::vector<std::string> altlocs;    // distinct conformer altlocs in order of appearance
+};
+
+}  // namespace arp
+
+// The parsed, filtered model (what `load_model` returns in the reference, utils.rs:51-63), as SoA columns.
+struct arp_structure {
+    uint64_t n = 0;
+    std::vector<double> x, y, z, occ;
+    std::vector<int32_t> serial, resi, model_serial;
+    arp::StrCol<8> name, resn /* conformer */, res_resn /* residue */, chain;
+    arp::StrCol<4> altloc, icode, elem;
+    std::vector<uint32_t> res_ord, res_id, base_attr, attr;
+    std::vector<uint16_t> chain_rank, model;
+    std::vector<uint32_t> atom_chain;  // index into chains
+    std::vector<arp::ChainInfo> chains;
+    std::vector<arp::ResidueInfo> residues;
+    std::vector<std::string> chain_ids;  // distinct ids, byte-wise sorted: chain_rank indexes this
+    std::vector<uint32_t> res_h_ptr, res_h_idx, res_cb, res_sg;
+    std::string groups_applied;
+    bool groups_valid = false;
+};
+
+namespace arp {
+arp_status parse_groups(const std::vector<std::string> &all_chains, const char *groups, std::vector<std::string> *ligand,
+                        std::vector<std::string> *receptor);
+arp_status apply_groups(arp_structure *s, const char *groups);
+bool fit_plane(const std::vector<std::array<double, 3>> &pts, Plane *out);
+}  // namespace arp

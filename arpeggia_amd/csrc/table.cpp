@@ -1,0 +1,384 @@
+// Table assembly: the product-side equivalent of `arpeggia::get_contacts` (src/contacts/mod.rs:61-137).
+// Atom-atom rows come from the GPU pair list (arp_contacts_atomic); ring planes, the low-volume ring rows
+// (complex.rs:301-405), side-chain plane statistics (complex.rs:137-174) and the 10-key sort (mod.rs:120-134) are
+// assembled here on the host in round 1 (SURVEY.md 8f rows f1/f2 move them to the device next).
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "host_common.h"
+
+namespace arp {
+
+// ---- plane maths (residues.rs:24-75, 270-298) ----------------------------------------------------------------------
+// Least-squares plane: centroid + eigenvector of the smallest eigenvalue of the 3x3 scatter matrix (cyclic Jacobi).
+// nalgebra's svd.u.column(2) is the same direction up to sign; every use folds the angle into [0, 90] degrees.
+bool fit_plane(const std::vector<std::array<double, 3>> &pts, Plane *out) {
+    const size_t n = pts.size();
+    if (n < 3) return false;  // residues.rs:273
+    double c[3] = {0, 0, 0};
+    for (auto &p : pts) for (int k = 0; k < 3; k++) c[k] += p[k];
+    for (int k = 0; k < 3; k++) c[k] /= (double)n;
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (auto &p : pts) {
+        double d[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] += d[i] * d[j];
+    }
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-18 * diag) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (fabs(A[p][q]) <= 1e-300) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; k++) { double akp = A[k][p], akq = A[k][q]; A[k][p] = cs * akp - sn * akq; A[k][q] = sn * akp + cs * akq; }
+                for (int k = 0; k < 3; k++) { double apk = A[p][k], aqk = A[q][k]; A[p][k] = cs * apk - sn * aqk; A[q][k] = sn * apk + cs * aqk; }
+                for (int k = 0; k < 3; k++) { double vkp = V[k][p], vkq = V[k][q]; V[k][p] = cs * vkp - sn * vkq; V[k][q] = sn * vkp + cs * vkq; }
+            }
+    }
+    int best = 0;
+    for (int k = 1; k < 3; k++) if (A[k][k] < A[best][best]) best = k;
+    double nn = sqrt(V[0][best] * V[0][best] + V[1][best] * V[1][best] + V[2][best] * V[2][best]);
+    for (int k = 0; k < 3; k++) { out->c[k] = c[k]; out->n[k] = V[k][best] / nn; }
+    return true;
+}
+static const double kRad2Deg = 180.0 / 3.14159265358979323846264338327950288;
+static double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+static double fold_deg(double rad) {  // residues.rs:50-53,70-73
+    if (rad > 1.57079632679489661923) rad = 3.14159265358979323846 - rad;
+    return rad * kRad2Deg;
+}
+static double point_dist(const Plane &p, const double q[3]) { double v[3] = {q[0] - p.c[0], q[1] - p.c[1], q[2] - p.c[2]}; return norm3(v); }
+static double point_angle(const Plane &p, const double q[3]) {
+    double v[3] = {q[0] - p.c[0], q[1] - p.c[1], q[2] - p.c[2]};
+    double dot = p.n[0] * v[0] + p.n[1] * v[1] + p.n[2] * v[2];
+    return fold_deg(acos(dot / (norm3(p.n) * norm3(v))));
+}
+static double plane_dihedral(const Plane &a, const Plane &b) {
+    double dot = a.n[0] * b.n[0] + a.n[1] * b.n[1] + a.n[2] * b.n[2];
+    return fold_deg(acos(dot / (norm3(a.n) * norm3(b.n))));
+}
+
+// ---- plane tables (complex.rs:442-514) ------------------------------------------------------------------------------
+static bool in_words(const char *words, const char *w) {
+    size_t L = strlen(w);
+    for (const char *p = words; *p;) {
+        const char *e = strchr(p, ' ');
+        size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len == L && strncmp(p, w, L) == 0) return true;
+        p += len;
+        while (*p == ' ') p++;
+    }
+    return false;
+}
+static const char *ring_atoms_of(const std::string &resn) {  // residues.rs:163-186
+    if (resn == "HIS") return "CG ND1 CE1 NE2 CD2";
+    if (resn == "PHE" || resn == "TYR") return "CG CD1 CD2 CE1 CE2 CZ";
+    if (resn == "TRP") return "CG CD1 CD2 NE1 CE2 CE3 CZ2 CZ3 CH2";
+    return nullptr;
+}
+static const char *sc_atoms_of(const std::string &resn) {  // residues.rs:188-268
+    static const std::map<std::string, const char *> m = {
+        {"ARG", "NE CZ NH1 NH2"}, {"ASN", "CB CG OD1 ND2"}, {"ASP", "CB CG OD1 OD2"}, {"CYS", "CA CB SG"}, {"GLU", "CG CD OE1 OE2"},
+        {"GLN", "CG CD OE1 NE2"}, {"ILE", "CB CG1 CG2 CD1"}, {"LEU", "CB CG CD1 CD2"}, {"LYS", "CG CD CE NZ"}, {"MET", "CG SD CE"},
+        {"PRO", "N CA CB CG CD"}, {"SER", "CA CB OG"}, {"THR", "CA CB OG1 CG2"}, {"VAL", "CA CB CG1 CG2"}};
+    if (const char *r = ring_atoms_of(resn)) return r;
+    auto it = m.find(resn);
+    return it == m.end() ? nullptr : it->second;
+}
+
+struct PlaneEntry {
+    int32_t model_serial; std::string chain; int32_t resi; std::string icode, altloc, resn;
+    Plane plane;
+    bool has_ord = false; uint32_t ord = 0;   // res2idx[(model, chain, resi, icode, altloc, resn)]
+    uint16_t chain_rank = 0; bool in_l = false, in_r = false;
+};
+using PlaneKey = std::tuple<int32_t, std::string, int32_t, std::string, std::string, std::string>;
+
+static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEntry> *out, std::map<PlaneKey, size_t> *index) {
+    std::vector<int32_t> serials;
+    for (const ChainInfo &c : s.chains) if (std::find(serials.begin(), serials.end(), c.model_serial) == serials.end()) serials.push_back(c.model_serial);
+    // res2idx: (model serial, chain, resi, icode) -> residue
+    std::map<std::tuple<int32_t, std::string, int32_t, std::string>, uint32_t> res_of;
+    for (uint32_t r = 0; r < s.residues.size(); r++) {
+        const ResidueInfo &ri = s.residues[r];
+        res_of[{s.chains[ri.chain].model_serial, s.chains[ri.chain].id, ri.resi, ri.icode}] = r;
+    }
+    // complex.rs:447-449 / 489-492: for EVERY model serial, ALL chains of ALL models are visited; later inserts overwrite
+    for (int32_t m : serials)
+        for (uint32_t r = 0; r < s.residues.size(); r++) {
+            const ResidueInfo &ri = s.residues[r];
+            const char *names = rings ? ring_atoms_of(ri.name) : sc_atoms_of(ri.name);
+            if (rings && !names) continue;
+            if (ri.atoms.empty()) continue;
+            std::vector<std::array<double, 3>> pts;
+            if (names) for (uint32_t a : ri.atoms) if (in_words(names, s.name.at(a))) pts.push_back({s.x[a], s.y[a], s.z[a]});
+            Plane pl;
+            if (!fit_plane(pts, &pl)) continue;  // complex.rs:471-474 warning path / :506 None
+            for (const std::string &alt : ri.altlocs) {
+                PlaneKey key{m, s.chains[ri.chain].id, ri.resi, ri.icode, alt, ri.name};
+                auto it = index->find(key);
+                if (it == index->end()) { it = index->emplace(key, out->size()).first; out->push_back(PlaneEntry{}); }
+                PlaneEntry &e = (*out)[it->second];
+                e.model_serial = m; e.chain = s.chains[ri.chain].id; e.resi = ri.resi; e.icode = ri.icode; e.altloc = alt; e.resn = ri.name;
+                e.plane = pl;
+            }
+        }
+    for (PlaneEntry &e : *out) {
+        auto it = res_of.find({e.model_serial, e.chain, e.resi, e.icode});
+        if (it == res_of.end()) continue;
+        const ResidueInfo &ri = s.residues[it->second];
+        if (ri.name != e.resn || std::find(ri.altlocs.begin(), ri.altlocs.end(), e.altloc) == ri.altlocs.end()) continue;
+        e.has_ord = true; e.ord = ri.ord;
+    }
+}
+
+// should_compare_residues (complex.rs:94-131) on prepared keys
+struct ResKey { int32_t model_serial; uint16_t chain_rank; uint32_t ord; bool in_l, in_r; };
+static bool compare_residues(const ResKey &a, const ResKey &b, bool symmetric) {
+    if (a.model_serial != b.model_serial) return false;
+    if (!((a.in_l && b.in_r) || (b.in_l && a.in_r))) return false;
+    if (a.chain_rank == b.chain_rank) {
+        if (symmetric) return (b.ord > 1) && (a.ord < b.ord - 1);
+        bool neigh = (a.ord == 0) ? (b.ord == a.ord || b.ord == a.ord + 1) : (b.ord == a.ord - 1 || b.ord == a.ord || b.ord == a.ord + 1);
+        return !neigh;
+    }
+    return !(symmetric && a.in_r && b.in_r && a.in_l && b.in_l && a.chain_rank > b.chain_rank);
+}
+
+}  // namespace arp
+
+using namespace arp;
+
+struct arp_table {
+    uint64_t n = 0;
+    std::vector<uint32_t> model;
+    std::vector<int32_t> interaction, from_resi, from_atomi, to_resi, to_atomi, from_atom, to_atom;
+    std::vector<float> distance, sc_dist, sc_dihedral, sc_angle;
+    std::vector<uint8_t> sc_valid;
+    StrCol<8> from_chain, from_resn, from_atomn, to_chain, to_resn, to_atomn;
+    StrCol<4> from_insertion, from_altloc, to_insertion, to_altloc;
+};
+
+namespace {
+struct Entity {  // structs.rs:55-70
+    std::string chain, resn, insertion, altloc, atomn;
+    int32_t resi = 0, atomi = 0, atom = -1;
+    uint16_t chain_rank = 0;
+    int64_t sc_plane = -1;
+};
+struct Row {
+    uint32_t model; int32_t interaction; double distance;
+    Entity from, to;
+};
+}  // namespace
+
+extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp, double dist_cutoff,
+                                       arp_table **out) {
+    if (!s || !out || !groups) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
+    *out = nullptr;
+    // InteractionComplex::new (complex.rs:36-68)
+    arp_atoms view;
+    arp_status st = arp_structure_atoms(s, groups, &view);
+    if (st != ARP_OK) return st;
+    std::vector<PlaneEntry> rings, scp;
+    std::map<PlaneKey, size_t> ring_idx, sc_idx;
+    build_planes(*s, true, &rings, &ring_idx);
+    if (rings.empty()) { set_error("Error building ring positions"); return ARP_ERR_NO_RINGS; }  // complex.rs:50
+    build_planes(*s, false, &scp, &sc_idx);
+    std::unordered_map<std::string, uint16_t> rank;
+    for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
+    std::vector<char> chain_l(s->chain_ids.size(), 0), chain_r(s->chain_ids.size(), 0);
+    for (size_t i = 0; i < s->n; i++) { chain_l[s->chain_rank[i]] = (s->attr[i] & ARP_ATTR_LIGAND) != 0; chain_r[s->chain_rank[i]] = (s->attr[i] & ARP_ATTR_RECEPTOR) != 0; }
+    {   // chains without atoms still belong to the sets
+        std::vector<std::string> L, R;
+        parse_groups(s->chain_ids, groups, &L, &R);
+        for (auto &c : L) chain_l[rank[c]] = 1;
+        for (auto &c : R) chain_r[rank[c]] = 1;
+    }
+    for (PlaneEntry &e : rings) { e.chain_rank = rank[e.chain]; e.in_l = chain_l[e.chain_rank]; e.in_r = chain_r[e.chain_rank]; }
+
+    // get_atomic_contacts (complex.rs:189-299): the GPU hot path
+    arp_params prm;
+    arp_default_params(&prm);
+    prm.vdw_comp = vdw_comp; prm.dist_cutoff = dist_cutoff;
+    arp_pairs pairs{};
+    st = arp_contacts_atomic(ctx, &view, &prm, ARP_MEM_HOST, &pairs);
+    if (st != ARP_OK) return st;
+
+    // per-atom side-chain plane lookup (the join key of mod.rs:100-110 plus resn, as in collect_sc_stats)
+    std::vector<int64_t> atom_sc(s->n, -1);
+    {
+        std::vector<int64_t> cache_res;  // per (residue, altloc) lookups are repeated per atom; memoise on residue id + altloc
+        std::map<std::pair<uint32_t, std::string>, int64_t> memo;
+        for (size_t a = 0; a < s->n; a++) {
+            auto key = std::make_pair(s->res_id[a], s->altloc.str(a));
+            auto it = memo.find(key);
+            if (it == memo.end()) {
+                auto f = sc_idx.find(PlaneKey{s->model_serial[a], s->chain.str(a), s->resi[a], s->icode.str(a), s->altloc.str(a), s->res_resn.str(a)});
+                it = memo.emplace(key, f == sc_idx.end() ? -1 : (int64_t)f->second).first;
+            }
+            atom_sc[a] = it->second;
+        }
+    }
+    auto entity_from_atom = [&](uint32_t a) {  // structs.rs:109-119
+        Entity e;
+        e.chain = s->chain.str(a); e.resn = s->res_resn.str(a); e.insertion = s->icode.str(a); e.altloc = s->altloc.str(a); e.atomn = s->name.str(a);
+        e.resi = s->resi[a]; e.atomi = s->serial[a]; e.atom = (int32_t)a; e.chain_rank = s->chain_rank[a]; e.sc_plane = atom_sc[a];
+        return e;
+    };
+    auto entity_from_ring = [&](const PlaneEntry &r) {  // complex.rs:334-342
+        Entity e;
+        e.chain = r.chain; e.resn = r.resn; e.insertion = r.icode; e.altloc = r.altloc; e.atomn = "Ring"; e.resi = r.resi; e.atomi = 0; e.atom = -1;
+        e.chain_rank = r.chain_rank;
+        auto f = sc_idx.find(PlaneKey{r.model_serial, r.chain, r.resi, r.icode, r.altloc, r.resn});
+        e.sc_plane = f == sc_idx.end() ? -1 : (int64_t)f->second;
+        return e;
+    };
+    std::vector<Row> rows;
+    rows.reserve(pairs.n / 8 + 64);
+    for (uint64_t k = 0; k < pairs.n; k++) {
+        const arp_pair &p = pairs.data[k];
+        if (!p.kind) continue;
+        for (int b = 0; b < ARP_N_INTERACTIONS; b++)
+            if (p.kind & (1u << b)) rows.push_back(Row{(uint32_t)s->model_serial[p.i], b, (double)p.dist, entity_from_atom(p.i), entity_from_atom(p.j)});
+    }
+    arp_pairs_free(&pairs);
+
+    // get_ring_atom_contacts (complex.rs:301-352) + find_cation_pi (aromatic.rs:14-29)
+    const double r2 = dist_cutoff * dist_cutoff;
+    {
+        // atoms that can ever produce a row are the few positively ionizable ones: index only those
+        std::vector<uint32_t> pos;
+        for (size_t a = 0; a < s->n; a++) if (s->attr[a] & ARP_ATTR_POS_RESN) pos.push_back((uint32_t)a);
+        for (const PlaneEntry &ring : rings) {
+            if (!ring.has_ord) continue;
+            ResKey rk{ring.model_serial, ring.chain_rank, ring.ord, ring.in_l, ring.in_r};
+            for (uint32_t a : pos) {
+                double q[3] = {s->x[a], s->y[a], s->z[a]};
+                double dx = q[0] - ring.plane.c[0], dy = q[1] - ring.plane.c[1], dz = q[2] - ring.plane.c[2];
+                if (!(dx * dx + dy * dy + dz * dz <= r2)) continue;
+                ResKey yk{s->model_serial[a], s->chain_rank[a], s->res_ord[a], (s->attr[a] & ARP_ATTR_LIGAND) != 0, (s->attr[a] & ARP_ATTR_RECEPTOR) != 0};
+                if (!compare_residues(rk, yk, false)) continue;
+                double dist = point_dist(ring.plane, q), theta = point_angle(ring.plane, q);
+                if (theta <= 30.0 && dist <= 4.5) rows.push_back(Row{(uint32_t)ring.model_serial, ARP_CationPi, dist, entity_from_ring(ring), entity_from_atom(a)});
+            }
+        }
+    }
+    // get_ring_ring_contacts (complex.rs:354-405) + find_pi_pi (aromatic.rs:33-64)
+    for (const PlaneEntry &k1 : rings) {
+        if (!k1.has_ord || !k1.in_l) continue;
+        ResKey r1{k1.model_serial, k1.chain_rank, k1.ord, k1.in_l, k1.in_r};
+        for (const PlaneEntry &k2 : rings) {
+            if (!k2.has_ord || !k2.in_r) continue;
+            double v[3] = {k1.plane.c[0] - k2.plane.c[0], k1.plane.c[1] - k2.plane.c[1], k1.plane.c[2] - k2.plane.c[2]};
+            double dist = norm3(v);
+            if (!(dist <= 6.0)) continue;
+            ResKey r2k{k2.model_serial, k2.chain_rank, k2.ord, k2.in_l, k2.in_r};
+            if (!compare_residues(r1, r2k, true)) continue;
+            double theta = point_angle(k1.plane, k2.plane.c), dih = plane_dihedral(k1.plane, k2.plane);
+            int code = -1;
+            if (dih <= 30.0) { if (theta <= 30.0) code = ARP_PiSandwichStacking; else if (theta <= 60.0) code = ARP_PiDisplacedStacking; else if (theta <= 90.0) code = ARP_PiParallelInPlaneStacking; }
+            else if (dih <= 60.0) code = ARP_PiTiltedStacking;
+            else if (dih <= 90.0) { if (theta >= 30.0 && theta < 60.0) code = ARP_PiLStacking; else if (dist <= 5.0) code = ARP_PiTStacking; }
+            if (code >= 0) rows.push_back(Row{(uint32_t)k1.model_serial, code, dist, entity_from_ring(k1), entity_from_ring(k2)});
+        }
+    }
+    // sort (mod.rs:120-134): model, from_chain, to_chain, from_resi, from_altloc, from_atomi, to_resi, to_altloc, to_atomi, interaction
+    int name_rank[ARP_N_INTERACTIONS];
+    {
+        std::vector<int> o(ARP_N_INTERACTIONS);
+        for (int k = 0; k < ARP_N_INTERACTIONS; k++) o[k] = k;
+        std::sort(o.begin(), o.end(), [](int a, int b) { return strcmp(arp_interaction_name(a), arp_interaction_name(b)) < 0; });
+        for (int k = 0; k < ARP_N_INTERACTIONS; k++) name_rank[o[k]] = k;
+    }
+    std::vector<uint32_t> order(rows.size());
+    for (size_t k = 0; k < rows.size(); k++) order[k] = (uint32_t)k;
+    std::sort(order.begin(), order.end(), [&](uint32_t ia, uint32_t ib) {
+        const Row &a = rows[ia], &b = rows[ib];
+        if (a.model != b.model) return a.model < b.model;
+        if (a.from.chain_rank != b.from.chain_rank) return a.from.chain_rank < b.from.chain_rank;
+        if (a.to.chain_rank != b.to.chain_rank) return a.to.chain_rank < b.to.chain_rank;
+        if (a.from.resi != b.from.resi) return a.from.resi < b.from.resi;
+        if (int c = a.from.altloc.compare(b.from.altloc)) return c < 0;
+        if (a.from.atomi != b.from.atomi) return a.from.atomi < b.from.atomi;
+        if (a.to.resi != b.to.resi) return a.to.resi < b.to.resi;
+        if (int c = a.to.altloc.compare(b.to.altloc)) return c < 0;
+        if (a.to.atomi != b.to.atomi) return a.to.atomi < b.to.atomi;
+        if (a.interaction != b.interaction) return name_rank[a.interaction] < name_rank[b.interaction];
+        // the reference's sort is unstable on full ties; break them deterministically
+        if (int c = a.from.insertion.compare(b.from.insertion)) return c < 0;
+        if (int c = a.to.insertion.compare(b.to.insertion)) return c < 0;
+        if (a.distance != b.distance) return a.distance < b.distance;
+        return ia < ib;
+    });
+    arp_table *t = new arp_table();
+    const size_t n = rows.size();
+    t->n = n;
+    t->model.resize(n); t->interaction.resize(n); t->from_resi.resize(n); t->from_atomi.resize(n); t->to_resi.resize(n); t->to_atomi.resize(n);
+    t->from_atom.resize(n); t->to_atom.resize(n); t->distance.resize(n); t->sc_dist.resize(n); t->sc_dihedral.resize(n); t->sc_angle.resize(n); t->sc_valid.resize(n);
+    t->from_chain.resize(n); t->from_resn.resize(n); t->from_atomn.resize(n); t->to_chain.resize(n); t->to_resn.resize(n); t->to_atomn.resize(n);
+    t->from_insertion.resize(n); t->from_altloc.resize(n); t->to_insertion.resize(n); t->to_altloc.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        const Row &r = rows[order[k]];
+        t->model[k] = r.model; t->interaction[k] = r.interaction; t->distance[k] = (float)r.distance;  // mod.rs:148
+        t->from_chain.set(k, r.from.chain.c_str()); t->from_resn.set(k, r.from.resn.c_str()); t->from_atomn.set(k, r.from.atomn.c_str());
+        t->from_insertion.set(k, r.from.insertion.c_str()); t->from_altloc.set(k, r.from.altloc.c_str());
+        t->from_resi[k] = r.from.resi; t->from_atomi[k] = r.from.atomi; t->from_atom[k] = r.from.atom;
+        t->to_chain.set(k, r.to.chain.c_str()); t->to_resn.set(k, r.to.resn.c_str()); t->to_atomn.set(k, r.to.atomn.c_str());
+        t->to_insertion.set(k, r.to.insertion.c_str()); t->to_altloc.set(k, r.to.altloc.c_str());
+        t->to_resi[k] = r.to.resi; t->to_atomi[k] = r.to.atomi; t->to_atom[k] = r.to.atom;
+        // collect_sc_stats (complex.rs:137-174): res1 = ligand residue, res2 = receptor residue
+        if (r.from.sc_plane >= 0 && r.to.sc_plane >= 0) {
+            const Plane &p1 = scp[r.from.sc_plane].plane, &p2 = scp[r.to.sc_plane].plane;
+            t->sc_valid[k] = 1;
+            t->sc_dist[k] = (float)point_dist(p1, p2.c);
+            t->sc_dihedral[k] = (float)plane_dihedral(p1, p2);
+            t->sc_angle[k] = (float)point_angle(p1, p2.c);
+        }
+    }
+    *out = t;
+    return ARP_OK;
+}
+
+extern "C" void arp_table_free(arp_table *t) { delete t; }
+extern "C" uint64_t arp_table_rows(const arp_table *t) { return t ? t->n : 0; }
+extern "C" const void *arp_table_column(const arp_table *t, const char *name, int32_t *width) {
+    if (!t || !name) return nullptr;
+    std::string c(name);
+    auto num = [&](const void *p, int w) -> const void * { if (width) *width = w; return p; };
+    if (c == "model") return num(t->model.data(), 4);
+    if (c == "interaction") return num(t->interaction.data(), 4);
+    if (c == "distance") return num(t->distance.data(), 4);
+    if (c == "from_resi") return num(t->from_resi.data(), 4);
+    if (c == "from_atomi") return num(t->from_atomi.data(), 4);
+    if (c == "to_resi") return num(t->to_resi.data(), 4);
+    if (c == "to_atomi") return num(t->to_atomi.data(), 4);
+    if (c == "from_atom") return num(t->from_atom.data(), 4);
+    if (c == "to_atom") return num(t->to_atom.data(), 4);
+    if (c == "sc_centroid_dist") return num(t->sc_dist.data(), 4);
+    if (c == "sc_dihedral") return num(t->sc_dihedral.data(), 4);
+    if (c == "sc_centroid_angle") return num(t->sc_angle.data(), 4);
+    if (c == "sc_valid") return num(t->sc_valid.data(), 1);
+    if (c == "from_chain") return num(t->from_chain.buf.data(), 8);
+    if (c == "from_resn") return num(t->from_resn.buf.data(), 8);
+    if (c == "from_atomn") return num(t->from_atomn.buf.data(), 8);
+    if (c == "to_chain") return num(t->to_chain.buf.data(), 8);
+    if (c == "to_resn") return num(t->to_resn.buf.data(), 8);
+    if (c == "to_atomn") return num(t->to_atomn.buf.data(), 8);
+    if (c == "from_insertion") return num(t->from_insertion.buf.data(), 4);
+    if (c == "from_altloc") return num(t->from_altloc.buf.data(), 4);
+    if (c == "to_insertion") return num(t->to_insertion.buf.data(), 4);
+    if (c == "to_altloc") return num(t->to_altloc.buf.data(), 4);
+    return nullptr;
+}

@@ -466,9 +466,11 @@ OrcStructure *orc_load_model(const char *path, int ignore_zero_occupancy) {
 }
 
 /* ------------------------------------------------------------------ parse_groups (utils.rs:71-115) */
-typedef struct { char (*ids)[8]; int n; } ChainSet;
+typedef struct { char (*ids)[8]; int n; int sorted; } ChainSet;
 
+static int cmp_id(const void *a, const void *b) { return strcmp((const char *)a, (const char *)b); }
 static int set_has(const ChainSet *s, const char *id) {
+    if (s->sorted) return bsearch(id, s->ids, (size_t)s->n, sizeof(char[8]), cmp_id) != NULL; /* many-chain inputs */
     for (int i = 0; i < s->n; i++) if (streq(s->ids[i], id)) return 1;
     return 0;
 }
@@ -503,7 +505,6 @@ static int parse_groups_sets(const ChainSet *all, const char *groups, ChainSet *
     if (lig->n == 0 || rec->n == 0) { set_err("Empty chain groups!"); return ORC_ERR_EMPTY_GROUPS; }
     return ORC_OK;
 }
-static int cmp_id(const void *a, const void *b) { return strcmp((const char *)a, (const char *)b); }
 static void emit_set(ChainSet *s, char *out, int cap, int *n) {
     qsort(s->ids, (size_t)s->n, sizeof(char[8]), cmp_id);
     int pos = 0; *n = 0;
@@ -527,6 +528,10 @@ static int structure_groups(const OrcStructure *s, const char *groups, ChainSet 
     for (int32_t c = 0; c < s->n_chains; c++) set_add(&all, s->chains[c].id);
     int rc = parse_groups_sets(&all, groups, lig, rec);
     free(all.ids);
+    if (rc == ORC_OK) {
+        qsort(lig->ids, (size_t)lig->n, sizeof(char[8]), cmp_id); lig->sorted = 1;
+        qsort(rec->ids, (size_t)rec->n, sizeof(char[8]), cmp_id); rec->sorted = 1;
+    }
     return rc;
 }
 
@@ -672,7 +677,7 @@ static int cmp_cell(const void *a, const void *b) {
 #define CELL_BITS 21
 static int64_t cell_key(int64_t cx, int64_t cy, int64_t cz) { return (cz << (2 * CELL_BITS)) | (cy << CELL_BITS) | cx; }
 static void grid_build(Grid *g, const OrcAtom *atoms, int32_t n, double edge) {
-    g->n = n; g->edge = edge > 1e-6 ? edge : 1e-6;
+    g->n = n; g->edge = edge > 1e-6 ? edge * 1.000001 : 1e-6; /* a hair above the cutoff: |dx| <= cutoff never skips a cell after rounding */
     g->ox = g->oy = g->oz = 0.0;
     for (int32_t i = 0; i < n; i++) {
         if (i == 0 || atoms[i].x < g->ox) g->ox = atoms[i].x;

@@ -1,0 +1,369 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): bit-exact contact-pair indices and interaction-type flags; distances within 1e-5 A.
+Run with `pytest -m gpu` on an MI355X box.  Reference citations are to y1zhou/arpeggia v0.8.0.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import arpeggia_amd as aa
+import oracle_binding as ob
+import synth
+from arpeggia_amd import _lib
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+DIST_TOL = 1e-5  # Angstrom
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert aa.device_count() >= 1, "no gfx950 device: the product has no CPU fallback"
+    return aa.Context(0)
+
+
+def canon(p):
+    return p[np.lexsort((p["j"], p["i"]))]
+
+
+def assert_pairs_equal(got, want, what=""):
+    """got: product pairs (PAIR_DTYPE); want: oracle pairs (i, j, dist f64, kind)."""
+    assert len(got) == len(want), f"{what}: {len(got)} pairs vs oracle {len(want)}"
+    g, w = canon(got), canon(want)
+    assert np.array_equal(g["i"], w["i"].astype(np.uint32)) and np.array_equal(g["j"], w["j"].astype(np.uint32)), f"{what}: pair indices differ"
+    bad = np.flatnonzero(g["kind"] != w["kind"])
+    assert len(bad) == 0, f"{what}: {len(bad)} kind mismatches, first: i={g['i'][bad[0]]} j={g['j'][bad[0]]} got={g['kind'][bad[0]]:#x} want={w['kind'][bad[0]]:#x} d={w['dist'][bad[0]]}"
+    assert np.abs(g["dist"].astype(np.float64) - w["dist"]).max(initial=0.0) <= DIST_TOL, f"{what}: distance tolerance"
+    # the table stores (f32) distance (mod.rs:148); report bit-exactness of that narrowing
+    return float((g["dist"] == w["dist"].astype(np.float32)).mean()) if len(g) else 1.0
+
+
+def run_both(ctx, prod, orc, groups="/", vdw_comp=0.1, cutoff=6.5):
+    got = ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff))
+    want = orc.atomic_contacts(groups, vdw_comp, cutoff)
+    return got, want
+
+
+# ---------------------------------------------------------------------------------------------- the two reference files
+@pytest.mark.parametrize("name,n_pairs", [("1ubq", 9128), ("6bft", 124047)])
+def test_reference_files_atomic_parity(ctx, name, n_pairs):
+    path = str(synth.DATA / f"{name}.pdb")
+    prod, orc = aa.load_model(path), ob.Structure.load(path)
+    got, want = run_both(ctx, prod, orc)
+    assert len(want) == n_pairs
+    exact = assert_pairs_equal(got, want, name)
+    assert exact == 1.0, f"f32 distances not bit-identical: {exact}"
+
+
+@pytest.mark.parametrize("groups", ["A/", "A,B/C,G", "H,L/H,L,A", "/G", "A,B,C,G,H,L/A,B,C,G,H,L", "G/G"])
+def test_6bft_chain_groups(ctx, groups):
+    path = str(synth.DATA / "6bft.pdb")
+    prod, orc = aa.load_model(path), ob.Structure.load(path)
+    got, want = run_both(ctx, prod, orc, groups)
+    assert len(want) > 0
+    assert_pairs_equal(got, want, groups)
+
+
+@pytest.mark.parametrize("vdw_comp,cutoff", [(0.1, 4.0), (0.0, 6.5), (0.25, 5.0), (0.1, 12.0), (1.0, 3.0), (0.1, 0.5), (0.1, 100.0)])
+def test_6bft_parameters(ctx, vdw_comp, cutoff):
+    path = str(synth.DATA / "6bft.pdb")
+    prod, orc = aa.load_model(path), ob.Structure.load(path)
+    if cutoff > 50:
+        path = str(synth.DATA / "1ubq.pdb")  # all-pairs regime: keep it small
+        prod, orc = aa.load_model(path), ob.Structure.load(path)
+    got, want = run_both(ctx, prod, orc, "/", vdw_comp, cutoff)
+    assert_pairs_equal(got, want, f"c={vdw_comp} d={cutoff}")
+
+
+# ---------------------------------------------------------------------------------------------- rule coverage
+@pytest.mark.parametrize("kw,groups", [
+    (dict(n_res=400, seed=7), "/"),
+    (dict(n_res=300, seed=8), "A,B/B,C,D"),
+    (dict(n_res=200, seed=9, n_models=3), "/"),
+    (dict(n_res=200, seed=10, altlocs=True), "A/"),
+    (dict(n_res=300, seed=11, hydrogens=False), "/"),
+])
+def test_stress_structures_cover_every_atomic_rule(ctx, kw, groups):
+    rec = synth.gen_stress(**kw)
+    prod = aa.Structure.from_records(rec)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+    got, want = run_both(ctx, prod, orc, groups)
+    assert_pairs_equal(got, want, str(kw))
+    if kw.get("hydrogens", True) and kw["n_res"] >= 300:
+        seen = np.bitwise_or.reduce(want["kind"])
+        for name in ("StericClash", "CovalentBond", "Disulfide", "VanDerWaalsContact", "IonicBond", "HydrogenBond", "WeakHydrogenBond",
+                     "PolarContact", "WeakPolarContact", "IonicRepulsion", "SaltBridge", "HydrophobicContact"):
+            assert seen & (1 << ob.INTERACTIONS.index(name)), f"stress input never produced {name}"
+
+
+def test_cys_without_cb_is_an_error_like_the_reference_panic(ctx):
+    # vdw.rs:55-58: cb1 = residue.atoms().find(CB).unwrap()
+    rec = synth.gen_stress(n_res=60, seed=21, hydrogens=False)
+    # two cysteines' SG atoms 2.05 A apart, CB removed
+    n = 4
+    extra = {k: v[:n].copy() for k, v in rec.items()}
+    extra["name"][:] = [b"SG", b"CA", b"SG", b"CA"]
+    extra["resn"][:] = b"CYS"
+    extra["element"][:] = [b"S", b"C", b"S", b"C"]
+    extra["chain"][:] = b"Z"
+    extra["resi"][:] = [1, 1, 5, 5]
+    extra["x"][:] = [500.0, 501.5, 502.05, 503.5]; extra["y"][:] = 500.0; extra["z"][:] = 500.0
+    extra["serial"][:] = np.arange(90001, 90001 + n)
+    rec2 = {k: np.concatenate([rec[k], extra[k]]) for k in rec}
+    prod = aa.Structure.from_records(rec2)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec2, flat=False), flat=False)
+    with pytest.raises(ob.OracleError):
+        orc.atomic_contacts()
+    with pytest.raises(aa.ArpeggiaError) as e:
+        ctx.atomic_contacts(prod.view("/"))
+    assert e.value.status == _lib.ARP_ERR_BAD_INPUT
+
+
+# ---------------------------------------------------------------------------------------------- synthetic clouds
+@pytest.mark.parametrize("gen,n", [("s2", 20000), ("s1", 20000), ("s2", 100000), ("s1", 100000)])
+def test_synthetic_clouds_vs_oracle(ctx, gen, n):
+    rec = getattr(synth, f"gen_{gen}")(n)
+    prod = aa.Structure.from_records(rec, hierarchy=True)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True)
+    got, want = run_both(ctx, prod, orc)
+    assert len(want) > 10 * n
+    assert_pairs_equal(got, want, f"{gen} {n}")
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+def _mini(xyz, names=None, resn=None, elems=None, chains=None, resi=None):
+    n = len(xyz)
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(n, 3)
+    return {
+        "x": xyz[:, 0].copy(), "y": xyz[:, 1].copy(), "z": xyz[:, 2].copy(), "occupancy": np.ones(n),
+        "serial": np.arange(1, n + 1, dtype=np.int32), "resi": np.asarray(resi if resi is not None else 10 * np.arange(1, n + 1), dtype=np.int32),
+        "model_serial": np.zeros(n, dtype=np.int32),
+        "name": np.asarray(names if names is not None else [b"CA"] * n, dtype="S8"), "resn": np.asarray(resn if resn is not None else [b"ALA"] * n, dtype="S8"),
+        "chain": np.asarray(chains if chains is not None else [b"A"] * n, dtype="S8"), "altloc": np.zeros(n, dtype="S4"), "icode": np.zeros(n, dtype="S4"),
+        "element": np.asarray(elems if elems is not None else [b"C"] * n, dtype="S4"),
+    }
+
+
+def _both_from(rec):
+    return aa.Structure.from_records(rec), ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+
+
+def test_empty_and_tiny_inputs(ctx):
+    zero = {k: np.zeros(0, dtype=d) for k, d in (("x", "f8"), ("y", "f8"), ("z", "f8"), ("attr", "u4"), ("res_ord", "u4"), ("chain_rank", "u2"), ("model", "u2"))}
+    assert len(ctx.atomic_contacts(zero)) == 0
+    prod, orc = _both_from(_mini([[1, 2, 3]]))
+    got, want = run_both(ctx, prod, orc)
+    assert len(got) == len(want) == 0
+    # residues 0 and 1 of one chain are sequence neighbours; 0 and 2 are not (complex.rs:113)
+    prod, orc = _both_from(_mini([[0, 0, 0], [3, 0, 0], [0, 3, 0]]))
+    got, want = run_both(ctx, prod, orc)
+    assert_pairs_equal(got, want)
+    assert len(got) == 1 and (got["i"][0], got["j"][0]) == (0, 2)
+
+
+def test_cutoff_is_inclusive(ctx):
+    # rstar locate_within_distance: d^2 <= r^2 (complex.rs:204)
+    c = 6.5
+    xyz = [[0, 0, 0], [50, 0, 0], [c, 0, 0], [50, c, 0], [100, 0, 0], [100, 0, np.nextafter(c, 10)]]
+    prod, orc = _both_from(_mini(xyz, chains=[b"A", b"A", b"B", b"B", b"A", b"B"]))
+    got, want = run_both(ctx, prod, orc)
+    assert_pairs_equal(got, want)
+    assert sorted(zip(got["i"].tolist(), got["j"].tolist())) == [(0, 2), (1, 3)]
+
+
+def test_all_hydrogen_and_coincident_atoms(ctx):
+    prod, orc = _both_from(_mini([[0, 0, 0], [1, 0, 0], [0, 1, 0]], names=[b"H1", b"H2", b"H3"], elems=[b"H"] * 3))
+    got, want = run_both(ctx, prod, orc)
+    assert len(got) == len(want) == 0
+    # 300 atoms on one point -> one cell with 300 members, every non-adjacent pair is a StericClash
+    prod, orc = _both_from(_mini(np.full((300, 3), 7.25)))
+    got, want = run_both(ctx, prod, orc)
+    assert_pairs_equal(got, want)
+    assert len(got) == 299 * 298 // 2 and (got["kind"] == 1).all()
+
+
+def test_sparse_huge_extent_and_large_coordinates(ctx):
+    rng = np.random.default_rng(5)
+    blobs = np.concatenate([rng.uniform(0, 12, size=(150, 3)) + o for o in ([0, 0, 0], [9000, -9000, 4000], [-9999, 9999, -9999], [5000, 5000, 5000])])
+    prod, orc = _both_from(_mini(np.round(blobs, 3)))
+    got, want = run_both(ctx, prod, orc)
+    assert len(want) > 1000
+    assert_pairs_equal(got, want)
+
+
+def test_bad_inputs_are_errors(ctx):
+    soa = aa.load_model(str(synth.DATA / "1ubq.pdb")).soa("/")
+    soa["x"][17] = np.nan
+    with pytest.raises(aa.ArpeggiaError) as e:
+        ctx.atomic_contacts(soa)
+    assert e.value.status == _lib.ARP_ERR_BAD_INPUT
+
+
+# ---------------------------------------------------------------------------------------------- size-independent properties
+def test_full_size_properties_1e6(ctx):
+    n = 1_000_000
+    rec = synth.gen_s2(n)
+    prod = aa.Structure.from_records(rec, hierarchy=True)
+    soa = prod.soa("/")
+    a = ctx.atomic_contacts(soa)
+    assert len(a) > 25 * n
+    # (1) determinism: the emitted order is a function of the input only
+    b = ctx.atomic_contacts(soa)
+    assert np.array_equal(a, b)
+    # (2) permutation invariance: shuffling the atoms changes indices only
+    perm = np.random.default_rng(1).permutation(n)
+    inv = np.empty(n, dtype=np.uint32); inv[perm] = np.arange(n, dtype=np.uint32)
+    shuffled = {k: (v[perm] if len(v) == n else v) for k, v in soa.items()}
+    shuffled["res_id"] = np.arange(n, dtype=np.uint32)  # one residue per atom; tables are per residue
+    for k in ("res_cb", "res_sg"):
+        shuffled[k] = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    shuffled["res_h_ptr"] = np.zeros(n + 1, dtype=np.uint32)
+    c = ctx.atomic_contacts(shuffled)
+    c2 = c.copy(); c2["i"] = perm[c["i"]]; c2["j"] = perm[c["j"]]
+    assert np.array_equal(canon(c2), canon(a))
+    # (3) a smaller cutoff yields the subset with identical flags (every rule threshold is <= 4.5 A)
+    d = ctx.atomic_contacts(soa, aa.default_params(0.1, 5.0))
+    ca = canon(a); cd = canon(d)
+    keep = ca["dist"].astype(np.float64) <= 5.0 - 1e-4
+    key = lambda p: p["i"].astype(np.uint64) << np.uint64(32) | p["j"].astype(np.uint64)
+    sel = np.isin(key(ca), key(cd))
+    assert (sel | ~keep).all()
+    assert np.array_equal(ca[sel], cd)
+    # (4) every flag bit implies its distance bound; candidates are within the cutoff
+    dist = a["dist"].astype(np.float64)
+    assert dist.max() <= 6.5 + 1e-5
+    for name, lim in (("HydrophobicContact", 4.5), ("IonicBond", 4.0), ("IonicRepulsion", 4.0), ("PolarContact", 3.5), ("WeakPolarContact", 3.5)):
+        m = (a["kind"] >> ob.INTERACTIONS.index(name)) & 1 == 1
+        assert dist[m].max(initial=0.0) <= lim + 1e-5
+    # (5) against the oracle at full size (seconds on one core)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True)
+    assert_pairs_equal(a, orc.atomic_contacts(), "s2 1e6")
+
+
+# ---------------------------------------------------------------------------------------------- enqueue / batch forms
+def test_enqueue_with_resident_buffers_and_capacity_error(ctx):
+    torch = pytest.importorskip("torch")
+    prod = aa.load_model(str(synth.DATA / "6bft.pdb"))
+    soa = prod.soa("/")
+    want = ctx.atomic_contacts(soa)
+    dev = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda() for k, v in soa.items()}
+    keep = []
+    atoms = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
+    prm = aa.default_params()
+    c2 = aa.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    out = torch.empty((len(want), 4), dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        c2.enqueue(atoms, prm, out.data_ptr(), len(want))
+        assert c2.result() == len(want)
+    got = out.cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1)
+    assert np.array_equal(got, want)
+    small = torch.zeros((1000, 4), dtype=torch.int32, device="cuda")
+    guard = small.clone()
+    c2.enqueue(atoms, prm, small.data_ptr(), 900)
+    with pytest.raises(aa.ArpeggiaError) as e:
+        c2.result()
+    assert e.value.status == _lib.ARP_ERR_CAPACITY and str(len(want)) in str(e.value)
+    assert torch.equal(small[900:], guard[900:])  # nothing written past the capacity
+    prof = None
+    c2.profile(True)
+    c2.enqueue(atoms, prm, out.data_ptr(), len(want)); c2.result()
+    prof = c2.profile_read()
+    assert "pairs_fill" in prof and all(v >= 0 for v in prof.values())
+
+
+def test_batch_of_structures(ctx):
+    recs = [synth.gen_s1(1500 + 400 * k, seed=100 + k) for k in range(5)]
+    structs = [aa.Structure.from_records(r, hierarchy=True) for r in recs]
+    views = [s.view("/") for s in structs]
+    singles = [ctx.atomic_contacts(v) for v in views]
+    arr = (C.POINTER(_lib.arp_atoms) * len(views))(*[C.pointer(v) for v in views])
+    outs = (_lib.arp_pairs * len(views))()
+    ctxs = (C.c_void_p * 1)(ctx._h)
+    prm = aa.default_params()
+    st = _lib.lib.arp_contacts_atomic_batch(ctxs, 1, arr, len(views), C.byref(prm), outs)
+    assert st == 0, _lib.lib.arp_last_error()
+    for k in range(len(views)):
+        buf = (C.c_char * (outs[k].n * 16)).from_address(outs[k].data)
+        got = np.frombuffer(buf, dtype=aa.PAIR_DTYPE).copy()
+        _lib.lib.arp_pairs_free(C.byref(outs[k]))
+        assert np.array_equal(got, singles[k])
+
+
+# ---------------------------------------------------------------------------------------------- the table (get_contacts)
+def _table_lines(cols):
+    out = []
+    names = _lib.INTERACTIONS
+    g = lambda v: repr(float(np.float32(v)))
+    for k in range(len(cols["model"])):
+        d = lambda c: cols[c][k].decode()
+        sc = (g(cols["sc_centroid_dist"][k]), g(cols["sc_dihedral"][k]), g(cols["sc_centroid_angle"][k])) if cols["sc_valid"][k] else ("", "", "")
+        out.append(",".join([str(cols["model"][k]), names[cols["interaction"][k]], g(cols["distance"][k]),
+                             d("from_chain"), d("from_resn"), str(cols["from_resi"][k]), d("from_insertion"), d("from_altloc"), d("from_atomn"), str(cols["from_atomi"][k]),
+                             d("to_chain"), d("to_resn"), str(cols["to_resi"][k]), d("to_insertion"), d("to_altloc"), d("to_atomn"), str(cols["to_atomi"][k]), *sc]))
+    return out
+
+
+def _lines_close(got, want):
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        fa, fb = a.split(","), b.split(",")
+        assert fa[:2] == fb[:2] and fa[3:17] == fb[3:17], (a, b)
+        for x, y, tol in ((fa[2], fb[2], DIST_TOL), (fa[17], fb[17], 1e-4), (fa[18], fb[18], 1e-2), (fa[19], fb[19], 1e-2)):
+            assert (x == "") == (y == ""), (a, b)
+            if x:
+                assert abs(float(x) - float(y)) <= tol, (a, b)
+
+
+@pytest.mark.parametrize("name,rows", [("1ubq", 532), ("6bft", 7236)])
+def test_table_matches_golden(ctx, name, rows):
+    # python/tests/test_arpeggia.py:32-35: 1ubq -> 532 rows; golden CSVs are restatement-derived (tests/golden/make_golden.py)
+    s = aa.load_model(str(synth.DATA / f"{name}.pdb"))
+    cols = ctx.get_contacts(s, "/", 0.1, 6.5)
+    assert len(cols["model"]) == rows
+    gold = (GOLDEN / f"{name}_contacts.csv").read_text().splitlines()[1:]
+    _lines_close(_table_lines(cols), gold)
+
+
+def test_contacts_drop_in_surface(ctx):
+    # python/tests/test_arpeggia.py:28-71
+    df = aa.contacts(str(synth.DATA / "1ubq.pdb"), groups="/", vdw_comp=0.1, dist_cutoff=6.5)
+    height = df.height if hasattr(df, "height") else df.num_rows
+    width = df.width if hasattr(df, "width") else df.num_columns
+    assert height == 532 and width == 20
+    cols = df.columns if hasattr(df, "columns") and not callable(df.columns) else df.column_names
+    assert list(cols) == [c for c, _ in aa.TABLE_COLUMNS]
+    import pyarrow as pa
+
+    if isinstance(df, pa.Table):
+        assert df.schema.field("model").type == pa.uint32() and df.schema.field("distance").type == pa.float32()
+        assert df.schema.field("from_resi").type == pa.int32() and df.schema.field("interaction").type == pa.string()
+        assert df.schema.field("sc_dihedral").type == pa.float32()
+        assert min(df.column("distance").to_pylist()) >= 0
+    # ignore_zero_occupancy is a no-op on 1ubq (test_arpeggia.py:85-112)
+    df2 = aa.contacts(str(synth.DATA / "1ubq.pdb"), ignore_zero_occupancy=True)
+    assert (df2.height if hasattr(df2, "height") else df2.num_rows) == 532
+
+
+def test_table_on_stress_structure_matches_oracle_table(ctx, tmp_path):
+    rec = synth.gen_stress(n_res=250, seed=31, n_chains=3)
+    p = tmp_path / "stress.pdb"
+    synth.write_pdb(rec, p)
+    s, o = aa.load_model(p), ob.Structure.load(p)
+    for groups in ("/", "A/B,C"):
+        cols = ctx.get_contacts(s, groups, 0.1, 6.5)
+        want = ob.rows_to_csv_lines(o.get_contacts(groups, 0.1, 6.5))
+        _lines_close(_table_lines(cols), want)
+
+
+def test_no_ring_structure_is_an_error(ctx):
+    # complex.rs:50,480-482: panics when the model has no HIS/PHE/TYR/TRP ring
+    prod, orc = _both_from(_mini([[0, 0, 0], [3, 0, 0], [0, 3, 0]]))
+    with pytest.raises(ob.OracleError) as eo:
+        orc.get_contacts()
+    assert eo.value.code == ob.ORC_ERR_NO_RINGS
+    with pytest.raises(aa.ArpeggiaError) as e:
+        ctx.get_contacts(prod)
+    assert e.value.status == _lib.ARP_ERR_NO_RINGS
