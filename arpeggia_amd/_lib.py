@@ -67,12 +67,34 @@ class arp_records(C.Structure):
     ]
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as the system one,
+    different file); if this library pulled in /opt/rocm's copy first and torch came later, the process would hold two
+    runtimes and torch would see no GPU (and its device pointers would be foreign to ours).  So when torch is installed,
+    its runtime is loaded first and libarpeggia_amd.so's DT_NEEDED libamdhip64.so.7 binds to it by SONAME.
+    ARPEGGIA_AMD_HIP_RUNTIME=/path/to/libamdhip64.so overrides the choice."""
+    import importlib.util
+    import os
+
+    path = os.environ.get("ARPEGGIA_AMD_HIP_RUNTIME")
+    if not path:
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+            if cand.exists():
+                path = str(cand)
+    if path:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
 def _load():
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or python arpeggia_amd/build.py). arpeggia_amd has no CPU fallback."
         )
+    _preload_hip_runtime()
     L = C.CDLL(str(LIB_PATH))
     vp = C.c_void_p
     sig = {

@@ -240,6 +240,15 @@ class Context:
         """Asynchronous, allocation-free form on device-resident data (arp_contacts_atomic_enqueue)."""
         _check(lib.arp_contacts_atomic_enqueue(self._h, C.byref(atoms), C.byref(params), C.c_void_p(out_ptr), capacity))
 
+    def count(self, atoms: _lib.arp_atoms, params: _lib.arp_params) -> int:
+        """Number of classified pairs without writing any (sizes the buffer for enqueue)."""
+        self.enqueue(atoms, params, 0, 0)
+        n = C.c_uint64()
+        st = lib.arp_contacts_atomic_result(self._h, C.byref(n))
+        if st not in (_lib.ARP_OK, _lib.ARP_ERR_CAPACITY):
+            _check(st)
+        return int(n.value)
+
     def result(self) -> int:
         n = C.c_uint64()
         st = lib.arp_contacts_atomic_result(self._h, C.byref(n))

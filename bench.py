@@ -108,13 +108,7 @@ def main():
     ctx = aa.Context(local_rank, stream=stream.cuda_stream)
 
     # size the output once (count pass), then everything is allocation-free
-    ctx.enqueue(atoms, prm, 0, 0)
-    try:
-        n_pairs = ctx.result()
-    except aa.ArpeggiaError as e:
-        if e.status != _lib.ARP_ERR_CAPACITY:
-            raise
-        n_pairs = int(str(e).split(":")[1].split()[0])
+    n_pairs = ctx.count(atoms, prm)
     out = torch.empty((n_pairs, 4), dtype=torch.int32, device=dev)
 
     def step():

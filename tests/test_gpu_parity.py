@@ -92,7 +92,7 @@ def test_stress_structures_cover_every_atomic_rule(ctx, kw, groups):
     orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
     got, want = run_both(ctx, prod, orc, groups)
     assert_pairs_equal(got, want, str(kw))
-    if kw.get("hydrogens", True) and kw["n_res"] >= 300:
+    if kw.get("hydrogens", True) and kw["n_res"] >= 400 and groups == "/":
         seen = np.bitwise_or.reduce(want["kind"])
         for name in ("StericClash", "CovalentBond", "Disulfide", "VanDerWaalsContact", "IonicBond", "HydrogenBond", "WeakHydrogenBond",
                      "PolarContact", "WeakPolarContact", "IonicRepulsion", "SaltBridge", "HydrophobicContact"):
@@ -108,7 +108,7 @@ def test_cys_without_cb_is_an_error_like_the_reference_panic(ctx):
     extra["name"][:] = [b"SG", b"CA", b"SG", b"CA"]
     extra["resn"][:] = b"CYS"
     extra["element"][:] = [b"S", b"C", b"S", b"C"]
-    extra["chain"][:] = b"Z"
+    extra["chain"][:] = [b"Y", b"Y", b"Z", b"Z"]
     extra["resi"][:] = [1, 1, 5, 5]
     extra["x"][:] = [500.0, 501.5, 502.05, 503.5]; extra["y"][:] = 500.0; extra["z"][:] = 500.0
     extra["serial"][:] = np.arange(90001, 90001 + n)
@@ -333,9 +333,10 @@ def test_contacts_drop_in_surface(ctx):
     height = df.height if hasattr(df, "height") else df.num_rows
     width = df.width if hasattr(df, "width") else df.num_columns
     assert height == 532 and width == 20
-    cols = df.columns if hasattr(df, "columns") and not callable(df.columns) else df.column_names
-    assert list(cols) == [c for c, _ in aa.TABLE_COLUMNS]
     import pyarrow as pa
+
+    cols = df.column_names if isinstance(df, pa.Table) else df.columns
+    assert list(cols) == [c for c, _ in aa.TABLE_COLUMNS]
 
     if isinstance(df, pa.Table):
         assert df.schema.field("model").type == pa.uint32() and df.schema.field("distance").type == pa.float32()
