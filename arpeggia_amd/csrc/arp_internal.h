@@ -32,8 +32,10 @@ struct GridParams {
     uint32_t nzt;         // total z layers = n_models * (nz + 1): each model gets its own slab + an empty separator
     uint32_t ncells;      // nx * ny * nzt
     uint32_t n_heavy;     // atoms in the grid (non-H)
+    uint32_t n_tasks;     // ceil(n_heavy / 64): one wave-task per 64 consecutive slots
     uint32_t bad;         // non-finite coordinate seen
     float prefilter_margin;
+    uint32_t pad;
 };
 
 struct Bounds {           // order-preserving u64 encodings of f64 min/max, reduced with atomics
@@ -52,11 +54,17 @@ struct DevAtoms {
     uint32_t n_res;
 };
 
+// Exact-phase record of one heavy atom, 48 B = three 16-byte loads.
+struct __attribute__((aligned(16))) Fat {
+    double x, y, z;
+    uint32_t attr, res_ord, crm /* chain_rank | model << 16 */, orig /* index into the caller's arrays */;
+};
+
 // Cell-sorted copy of the heavy atoms (slot order: x-major cells, atoms of a cell in ascending input index).
 struct Sorted {
-    float4 *rec;          // {x-ox, y-oy, z-oz as f32, bits(original atom index)}  -- prefilter operand, 16 B
-    double *x, *y, *z;    // exact coordinates for the f64 decision
-    uint4 *meta;          // {attr, res_ord, chain_rank | model << 16, original index}
+    float4 *rec;          // {x-ox, y-oy, z-oz as f32, bits(cell id)}  -- prefilter operand, 16 B
+    Fat *fat;
+    uint2 *hinfo;         // [begin, end) of the residue's hydrogens in res_h_idx
 };
 
 struct Workspace {
@@ -64,27 +72,20 @@ struct Workspace {
     GridParams *grid;
     DevParams *params;
     uint32_t *cell_of_atom;   // n
+    uint32_t *rank_of_atom;   // n: arrival rank inside the cell (returning atomic)
     uint32_t *cell_count;     // ncells_cap + 1
     uint32_t *cell_start;     // ncells_cap + 1
-    uint32_t *cell_fill;      // ncells_cap
-    uint32_t *perm;           // n: slot -> atom (unordered inside a cell)
+    uint32_t *perm;           // n: slot -> atom (arrival order inside a cell)
     uint32_t *slot_cell;      // n
     Sorted sorted;
-    uint32_t *task_count;     // ncells_cap + 1: candidate pairs per home cell
-    unsigned long long *task_base;  // ncells_cap + 1
+    uint32_t *task_count;     // n/64 + 2: candidate pairs per wave-task
+    unsigned long long *task_base;  // n/64 + 2
     uint32_t *scan_tmp;       // block sums (1024 + 1)
     unsigned long long *scan_tmp64;
-    unsigned long long *result;  // [0] = total pairs, [1] = overflow flag
+    unsigned long long *result;  // [0] = total pairs, [1] = flags
     uint32_t ncells_cap;
     uint32_t n_cap;
 };
-
-// Launch wrappers (kernels.hip).  All asynchronous on `st`.
-struct Profiler;
-void launch_pipeline(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
-                     bool fill, Profiler *prof, double cutoff);
-void launch_fill_only(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
-                      Profiler *prof);
 
 struct Profiler {
     static constexpr int kMax = 32;
@@ -96,5 +97,11 @@ struct Profiler {
     void begin(const char *name, hipStream_t st);
     void end(hipStream_t st);
 };
+
+// Launch wrappers (kernels.hip).  All asynchronous on `st`.
+void launch_pipeline(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
+                     bool fill, Profiler *prof, double cutoff);
+void launch_fill_only(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
+                      Profiler *prof);
 
 }  // namespace arp

@@ -132,10 +132,10 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     arp_status s;
 #define A(ptr, cnt) if ((s = dev_alloc(ctx, &(ptr), (cnt))) != ARP_OK) { free_workspace(ctx); return s; }
     A(w.bounds, 1); A(w.grid, 1); A(w.params, 1);
-    A(w.cell_of_atom, cap); A(w.cell_count, ccap + 1); A(w.cell_start, ccap + 1); A(w.cell_fill, ccap + 1);
+    A(w.cell_of_atom, cap); A(w.rank_of_atom, cap); A(w.cell_count, ccap + 1); A(w.cell_start, ccap + 1);
     A(w.perm, cap); A(w.slot_cell, cap);
-    A(w.sorted.rec, cap); A(w.sorted.x, cap); A(w.sorted.y, cap); A(w.sorted.z, cap); A(w.sorted.meta, cap);
-    A(w.task_count, ccap + 1); A(w.task_base, ccap + 1);
+    A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.hinfo, cap);
+    A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 2);
 #undef A
     w.n_cap = (uint32_t)cap;
@@ -189,7 +189,7 @@ extern "C" arp_status arp_context_set_stream(arp_context *ctx, void *hip_stream)
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
     return ARP_OK;
 }
 

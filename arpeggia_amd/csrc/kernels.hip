@@ -2,7 +2,7 @@
 //
 // Pipeline (all on one stream, no host round trip):
 //   k_init -> k_bounds -> k_setup -> k_zero_cells -> k_cellid -> scan(cell_count) -> k_scatter -> k_gather
-//   -> k_pairs<COUNT> -> scan(task_count) -> k_pairs<FILL>
+//   -> k_pairs<COUNT> -> scan(task_count) -> k_finish -> k_pairs<FILL>
 // It replaces the reference's R*-tree build + serial neighbour walk + rayon classification
 // (src/contacts/complex.rs:189-299) with a uniform-grid cell list and a count/scan/fill pair emitter whose
 // output order is deterministic.  Decisions are made in f64 with the reference's operation order and no FMA
@@ -22,7 +22,6 @@ DEVFN double dec_f64(unsigned long long e) {
     unsigned long long u = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
     return __longlong_as_double((long long)u);
 }
-DEVFN uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // number of set bits of `mask` below this lane
 DEVFN uint32_t mbcnt(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -32,6 +31,16 @@ DEVFN double sq_dist(double ax, double ay, double az, double bx, double by, doub
     double dx = __dsub_rn(bx, ax), dy = __dsub_rn(by, ay), dz = __dsub_rn(bz, az);
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
+DEVFN uint32_t wave_min_u32(uint32_t v) {
+    for (int off = 32; off; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
+}
+DEVFN uint32_t wave_max_u32(uint32_t v) {
+    for (int off = 32; off; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
+}
+DEVFN void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+constexpr uint32_t kAttrResHasH = 0x80000000u;  // internal: the atom's residue carries hydrogens (set by k_gather)
 
 // ---------------------------------------------------------------------------------------------- grid build
 __global__ void k_init(Bounds *b, unsigned long long *result) {
@@ -39,7 +48,10 @@ __global__ void k_init(Bounds *b, unsigned long long *result) {
     if (threadIdx.x == 0) { b->n_models = 0; b->bad = 0; result[0] = 0; result[1] = 0; }
 }
 
+// Bounding box of the heavy atoms: registers -> wave shuffles -> LDS -> one atomic set per block (<= 256 blocks).
 __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, Bounds *b) {
+    __shared__ double s_mn[4][3], s_mx[4][3];
+    __shared__ uint32_t s_models[4], s_bad[4];
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t models = 0, bad = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += gridDim.x * blockDim.x) {
@@ -60,12 +72,21 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, Bounds *b) {
         models = max(models, (uint32_t)__shfl_xor((int)models, off));
         bad |= (uint32_t)__shfl_xor((int)bad, off);
     }
+    const uint32_t w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 3; k++) {
-            if (mn[k] <= mx[k]) { atomicMin(&b->mn[k], enc_f64(mn[k])); atomicMax(&b->mx[k], enc_f64(mx[k])); }
-        }
-        atomicMax(&b->n_models, models);
-        if (bad) atomicOr(&b->bad, 1u);
+        for (int k = 0; k < 3; k++) { s_mn[w][k] = mn[k]; s_mx[w][k] = mx[k]; }
+        s_models[w] = models; s_bad[w] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        double a = fmin(fmin(s_mn[0][k], s_mn[1][k]), fmin(s_mn[2][k], s_mn[3][k]));
+        double c = fmax(fmax(s_mx[0][k], s_mx[1][k]), fmax(s_mx[2][k], s_mx[3][k]));
+        if (a <= c) { atomicMin(&b->mn[k], enc_f64(a)); atomicMax(&b->mx[k], enc_f64(c)); }
+    }
+    if (threadIdx.x == 3) {
+        atomicMax(&b->n_models, max(max(s_models[0], s_models[1]), max(s_models[2], s_models[3])));
+        if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) atomicOr(&b->bad, 1u);
     }
 }
 
@@ -94,6 +115,7 @@ __global__ void k_setup(const Bounds *b, GridParams *g, DevParams *prm, double c
     g->nx = (uint32_t)nx; g->ny = (uint32_t)ny; g->nz = (uint32_t)nz;
     g->nzt = nm * (g->nz + 1u);
     g->ncells = g->nx * g->ny * g->nzt;
+    g->n_heavy = 0; g->n_tasks = 0;
     g->bad = b->bad;
     // f32 prefilter: relative coordinates carry <= 2^-24 * extent of rounding each; a 10x-safe bound on the
     // induced error of dx^2+dy^2+dz^2 near the cutoff (derivation in DESIGN.md "Prefilter margin")
@@ -103,12 +125,9 @@ __global__ void k_setup(const Bounds *b, GridParams *g, DevParams *prm, double c
     prm->r2f = __double2float_ru(prm->r2 + margin);
 }
 
-__global__ __launch_bounds__(256) void k_zero_cells(const GridParams *g, uint32_t *cell_count, uint32_t *cell_fill) {
+__global__ __launch_bounds__(256) void k_zero_cells(const GridParams *g, uint32_t *cell_count) {
     uint32_t n = g->ncells;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
-        cell_count[i] = 0;
-        if (i < n) cell_fill[i] = 0;
-    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) cell_count[i] = 0;
 }
 
 DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
@@ -122,16 +141,19 @@ DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uin
     return (layer * g.ny + cy) * g.nx + cx;
 }
 
-__global__ __launch_bounds__(256) void k_cellid(DevAtoms in, const GridParams *gp, uint32_t *cell_of_atom, uint32_t *cell_count) {
+// One returning atomic per atom: the old value is the atom's arrival rank in its cell, so the scatter needs none.
+__global__ __launch_bounds__(256) void k_cellid(DevAtoms in, const GridParams *gp, uint32_t *cell_of_atom, uint32_t *rank_of_atom,
+                                                uint32_t *cell_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= in.n) return;
     GridParams g = *gp;
-    uint32_t c = ARP_NONE;
+    uint32_t c = ARP_NONE, r = 0;
     if (!(in.attr[i] & ARP_ATTR_H)) {
         c = cell_index(g, in.x[i], in.y[i], in.z[i], in.model[i]);
-        atomicAdd(&cell_count[c], 1u);
+        r = atomicAdd(&cell_count[c], 1u);
     }
     cell_of_atom[i] = c;
+    rank_of_atom[i] = r;
 }
 
 // ---------------------------------------------------------------------------------------------- scan
@@ -141,7 +163,6 @@ constexpr uint32_t kScanBlocks = 1024, kScanThreads = 256;
 
 template <typename TOut>
 DEVFN TOut block_exclusive_scan(TOut v, TOut *total, TOut *lds /* [kScanThreads/64 + 1] */) {
-    // wave inclusive scan
     TOut inc = v;
     for (int off = 1; off < 64; off <<= 1) {
         TOut t = __shfl_up(inc, off);
@@ -201,45 +222,62 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t *in,
 }
 
 // ---------------------------------------------------------------------------------------------- sort into cells
-__global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *cell_of_atom, const uint32_t *cell_start,
-                                                 uint32_t *cell_fill, uint32_t *perm, uint32_t *slot_cell) {
+__global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *cell_of_atom, const uint32_t *rank_of_atom,
+                                                 const uint32_t *cell_start, uint32_t *perm, uint32_t *slot_cell) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t c = cell_of_atom[i];
     if (c == ARP_NONE) return;
-    uint32_t p = cell_start[c] + atomicAdd(&cell_fill[c], 1u);
+    uint32_t p = cell_start[c] + rank_of_atom[i];
     perm[p] = i;
     slot_cell[p] = c;
 }
 
 // Final slot = cell_start + rank of the atom index inside its cell: the sorted order (and therefore the order of
 // the emitted pairs) does not depend on the arrival order of the atomics above.
-__global__ __launch_bounds__(256) void k_gather(DevAtoms in, const GridParams *gp, const uint32_t *cell_start,
-                                                const uint32_t *perm, const uint32_t *slot_cell, Sorted so) {
+__global__ __launch_bounds__(256) void k_gather(DevAtoms in, GridParams *gp, const uint32_t *cell_start, const uint32_t *perm,
+                                                const uint32_t *slot_cell, Sorted so) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    GridParams g = *gp;
-    uint32_t n_heavy = cell_start[g.ncells];
+    const uint32_t ncells = gp->ncells;
+    uint32_t n_heavy = cell_start[ncells];
+    if (p == 0) { gp->n_heavy = n_heavy; gp->n_tasks = (n_heavy + 63u) / 64u; }
     if (p >= n_heavy) return;
     uint32_t c = slot_cell[p], i = perm[p];
     uint32_t s = cell_start[c], e = cell_start[c + 1], rank = 0;
     for (uint32_t q = s; q < e; q++) rank += (perm[q] < i) ? 1u : 0u;
     uint32_t d = s + rank;
     double x = in.x[i], y = in.y[i], z = in.z[i];
-    so.x[d] = x; so.y[d] = y; so.z[d] = z;
-    so.rec[d] = make_float4((float)(x - g.ox), (float)(y - g.oy), (float)(z - g.oz), __uint_as_float(i));
-    so.meta[d] = make_uint4(in.attr[i], in.res_ord[i], (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16), i);
+    so.rec[d] = make_float4((float)(x - gp->ox), (float)(y - gp->oy), (float)(z - gp->oz), __uint_as_float(c));
+    Fat f;
+    f.x = x; f.y = y; f.z = z;
+    f.attr = in.attr[i] & ~kAttrResHasH; f.res_ord = in.res_ord[i]; f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i;
+    // Resolve the residue -> hydrogens indirection once per atom: the pair kernel touches the hydrogen tables only for
+    // donors whose residue really carries hydrogens (hbond.rs:38-42), with no dependent loads on the common path.
+    uint2 hi = make_uint2(0u, 0u);
+    if (in.n_res) {
+        const uint32_t r = in.res_id[i];
+        hi.x = in.res_h_ptr[r]; hi.y = in.res_h_ptr[r + 1];
+        if (hi.x < hi.y) f.attr |= kAttrResHasH;
+    }
+    so.hinfo[d] = hi;
+    so.fat[d] = f;
 }
 
 // ---------------------------------------------------------------------------------------------- per-pair rules
+struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB)
+    double s_clash[256], s_cov[256], s_vdw[256], s_hacc[16];
+    double r2, s_ion, s_polar, s_hphob;
+};
+
 // should_compare_entities(x, y, symmetric = true) for x in L, y in R (complex.rs:76-131, 200-206); hydrogens never
 // reach here (they are not in the grid).
-DEVFN bool candidate(uint4 mx, uint4 my) {
-    if (!(mx.x & ARP_ATTR_LIGAND) || !(my.x & ARP_ATTR_RECEPTOR)) return false;
-    if ((mx.z >> 16) != (my.z >> 16)) return false;                      // :96-98 same model
-    if ((mx.z & 0xFFFFu) == (my.z & 0xFFFFu))                            // :108 same chain
-        return (my.y > 1u) && (mx.y < my.y - 1u);                        // :113
-    bool both = (mx.x & my.x & ARP_ATTR_LIGAND) && (mx.x & my.x & ARP_ATTR_RECEPTOR);
-    return !(both && ((mx.z & 0xFFFFu) > (my.z & 0xFFFFu)));             // :124-129
+DEVFN bool candidate(const Fat &x, const Fat &y) {
+    if (!(x.attr & ARP_ATTR_LIGAND) || !(y.attr & ARP_ATTR_RECEPTOR)) return false;
+    if ((x.crm >> 16) != (y.crm >> 16)) return false;                    // :96-98 same model
+    if ((x.crm & 0xFFFFu) == (y.crm & 0xFFFFu))                          // :108 same chain
+        return (y.res_ord > 1u) && (x.res_ord < y.res_ord - 1u);         // :113
+    bool both = (x.attr & y.attr & ARP_ATTR_LIGAND) && (x.attr & y.attr & ARP_ATTR_RECEPTOR);
+    return !(both && ((x.crm & 0xFFFFu) > (y.crm & 0xFFFFu)));           // :124-129
 }
 
 DEVFN double angle_deg(const double a[3], const double b[3], const double c[3]) {
@@ -260,199 +298,275 @@ DEVFN double dihedral_deg(const double a[3], const double b[3], const double c[3
     double dot = 0.0 + n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
     return acos(dot / (a1 * a2)) * (180.0 / 3.14159265358979323846264338327950288);
 }
-DEVFN void load_pos(const DevAtoms &in, uint32_t i, double p[3]) { p[0] = in.x[i]; p[1] = in.y[i]; p[2] = in.z[i]; }
 
 // hbond.rs:36-63 / 80-107 for a fixed (donor, acceptor) assignment.  Returns 2 = (weak) hydrogen bond,
-// 1 = (weak) polar contact, 0 = nothing.
-DEVFN int hbond_like(const DevAtoms &in, const DevParams *prm, double s, uint32_t donor_idx, const double pd[3],
-                     const double pa[3], uint32_t acc_attr, double min_angle) {
-    if (s < prm->s_ion && in.n_res) {  // da_dist <= 4.0: probe every hydrogen of the donor's residue (hbond.rs:38-42)
-        uint32_t r = in.res_id[donor_idx];
-        uint32_t p0 = in.res_h_ptr[r], p1 = in.res_h_ptr[r + 1];
-        double lim = prm->s_hacc[acc_attr & ARP_ATTR_ELEM_MASK];
-        for (uint32_t p = p0; p < p1; p++) {
-            double ph[3];
-            load_pos(in, in.res_h_idx[p], ph);
-            if (sq_dist(ph[0], ph[1], ph[2], pa[0], pa[1], pa[2]) < lim && angle_deg(pd, ph, pa) >= min_angle) return 2;
-        }
+// 1 = (weak) polar contact, 0 = nothing.  The hydrogen probe is out of line: it runs only for donor residues that
+// actually carry hydrogens.
+__device__ __noinline__ int hydrogen_probe(const double *X, const double *Y, const double *Z, const uint32_t *res_h_idx, double lim,
+                                           uint32_t p0, uint32_t p1, double dx, double dy, double dz, double ax, double ay, double az,
+                                           double min_angle) {
+    const double pd[3] = {dx, dy, dz}, pa[3] = {ax, ay, az};
+    for (uint32_t p = p0; p < p1; p++) {
+        const uint32_t h = res_h_idx[p];
+        const double ph[3] = {X[h], Y[h], Z[h]};
+        if (sq_dist(ph[0], ph[1], ph[2], pa[0], pa[1], pa[2]) < lim && angle_deg(pd, ph, pa) >= min_angle) return 1;
     }
-    return (s < prm->s_polar) ? 1 : 0;
+    return 0;
+}
+DEVFN int hbond_like(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, const Fat &donor, uint32_t donor_slot,
+                     const Fat &acc, double min_angle) {
+    if ((donor.attr & kAttrResHasH) && s < prm.s_ion) {  // da_dist <= 4.0: probe every hydrogen of the donor's residue (hbond.rs:38-42)
+        const uint2 hi = hinfo[donor_slot];
+        if (hydrogen_probe(in.x, in.y, in.z, in.res_h_idx, prm.s_hacc[acc.attr & ARP_ATTR_ELEM_MASK], hi.x, hi.y, donor.x, donor.y, donor.z, acc.x, acc.y, acc.z, min_angle))
+            return 2;
+    }
+    return (s < prm.s_polar) ? 1 : 0;
+}
+
+// vdw.rs:46-80, out of line (rare): 1 = disulfide, 0 = plain covalent, sets the error flag where the reference panics
+__device__ __noinline__ int disulfide_probe(const double *X, const double *Y, const double *Z, const uint32_t *res_id, const uint32_t *res_cb,
+                                            const uint32_t *res_sg, uint32_t ix, uint32_t iy, unsigned long long *result) {
+    uint32_t r1 = res_id[ix], r2 = res_id[iy];
+    uint32_t cb1 = res_cb[r1], s1 = res_sg[r1], s2 = res_sg[r2], cb2 = res_cb[r2];
+    if (cb1 == ARP_NONE || cb2 == ARP_NONE || s1 == ARP_NONE || s2 == ARP_NONE) {
+        atomicOr(&result[1], 2ull);  // the reference unwrap()s and panics here
+        return 0;
+    }
+    const double a[3] = {X[cb1], Y[cb1], Z[cb1]}, b[3] = {X[s1], Y[s1], Z[s1]}, c[3] = {X[s2], Y[s2], Z[s2]}, d[3] = {X[cb2], Y[cb2], Z[cb2]};
+    double dih = fabs(dihedral_deg(a, b, c, d));
+    return (dih >= 60.0) && (dih <= 120.0);
 }
 
 // All rows of one candidate pair as a bit set (complex.rs:217-296).  x = ligand, y = receptor.
-DEVFN uint32_t classify(const DevAtoms &in, const DevParams *prm, double s, uint4 mx, uint4 my, const double px[3],
-                        const double py[3], unsigned long long *result) {
-    const uint32_t ax = mx.x, ay = my.x;
+DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, const Fat &x, uint32_t sx, const Fat &y,
+                        uint32_t sy, unsigned long long *result) {
+    const uint32_t ax = x.attr, ay = y.attr;
     const uint32_t e = ((ax & ARP_ATTR_ELEM_MASK) << 4) | (ay & ARP_ATTR_ELEM_MASK);
     uint32_t kind = 0;
     // vdw.rs:32-43
-    if (s < prm->s_clash[e]) return 1u << ARP_StericClash;  // complex.rs:233-235: nothing else is looked at
-    if (s < prm->s_cov[e]) {
-        bool ss = false;
-        if ((ax & ay & ARP_ATTR_CYS_SG) && in.n_res) {  // vdw.rs:46-80
-            uint32_t r1 = in.res_id[mx.w], r2 = in.res_id[my.w];
-            uint32_t cb1 = in.res_cb[r1], s1 = in.res_sg[r1], s2 = in.res_sg[r2], cb2 = in.res_cb[r2];
-            if (cb1 == ARP_NONE || cb2 == ARP_NONE || s1 == ARP_NONE || s2 == ARP_NONE) {
-                atomicOr(&result[1], 2ull);  // the reference unwrap()s and panics here
-            } else {
-                double a[3], b[3], c[3], d[3];
-                load_pos(in, cb1, a); load_pos(in, s1, b); load_pos(in, s2, c); load_pos(in, cb2, d);
-                double dih = fabs(dihedral_deg(a, b, c, d));
-                ss = (dih >= 60.0) && (dih <= 120.0);
-            }
-        }
+    if (s < prm.s_clash[e]) return 1u << ARP_StericClash;  // complex.rs:233-235: nothing else is looked at
+    if (s < prm.s_cov[e]) {
+        int ss = 0;
+        if ((ax & ay & ARP_ATTR_CYS_SG) && in.n_res) ss = disulfide_probe(in.x, in.y, in.z, in.res_id, in.res_cb, in.res_sg, x.orig, y.orig, result);
         kind |= 1u << (ss ? ARP_Disulfide : ARP_CovalentBond);
-    } else if (s < prm->s_vdw[e]) {
+    } else if (s < prm.s_vdw[e]) {
         kind |= 1u << ARP_VanDerWaalsContact;
     }
-    const bool near4 = s < prm->s_ion;  // d <= 4.0
+    const bool near4 = s < prm.s_ion;  // d <= 4.0
     // ionic.rs:11-22,37-57
     const bool ionic = near4 && (((ax & ARP_ATTR_POS) && (ay & ARP_ATTR_NEG)) || ((ay & ARP_ATTR_POS) && (ax & ARP_ATTR_NEG)));
     // hbond.rs:30-66,113-134: (e1 donor, e2 acceptor) is tried first
     int hb = 0;
-    if ((ax & ARP_ATTR_DONOR) && (ay & ARP_ATTR_ACCEPTOR)) hb = hbond_like(in, prm, s, mx.w, px, py, ay, 90.0);
-    else if ((ay & ARP_ATTR_DONOR) && (ax & ARP_ATTR_ACCEPTOR)) hb = hbond_like(in, prm, s, my.w, py, px, ax, 90.0);
+    if ((ax & ARP_ATTR_DONOR) && (ay & ARP_ATTR_ACCEPTOR)) hb = hbond_like(in, prm, hinfo, s, x, sx, y, 90.0);
+    else if ((ay & ARP_ATTR_DONOR) && (ax & ARP_ATTR_ACCEPTOR)) hb = hbond_like(in, prm, hinfo, s, y, sy, x, 90.0);
     // complex.rs:240-251
     if (ionic) kind |= 1u << (hb == 2 ? ARP_SaltBridge : ARP_IonicBond);
     else if (hb) kind |= 1u << (hb == 2 ? ARP_HydrogenBond : ARP_PolarContact);
     // hbond.rs:74-110,181-201
     int wk = 0;
-    if ((ax & ARP_ATTR_WEAK_DONOR) && (ay & ARP_ATTR_ACCEPTOR)) wk = hbond_like(in, prm, s, mx.w, px, py, ay, 130.0);
-    else if ((ay & ARP_ATTR_WEAK_DONOR) && (ax & ARP_ATTR_ACCEPTOR)) wk = hbond_like(in, prm, s, my.w, py, px, ax, 130.0);
+    if ((ax & ARP_ATTR_WEAK_DONOR) && (ay & ARP_ATTR_ACCEPTOR)) wk = hbond_like(in, prm, hinfo, s, x, sx, y, 130.0);
+    else if ((ay & ARP_ATTR_WEAK_DONOR) && (ax & ARP_ATTR_ACCEPTOR)) wk = hbond_like(in, prm, hinfo, s, y, sy, x, 130.0);
     if (wk) kind |= 1u << (wk == 2 ? ARP_WeakHydrogenBond : ARP_WeakPolarContact);
     // ionic.rs:25-35,59-81
     if (near4 && ((ax & ay & ARP_ATTR_POS) || (ax & ay & ARP_ATTR_NEG))) kind |= 1u << ARP_IonicRepulsion;
     // hydrophobic.rs:10-24
-    if ((ax & ay & ARP_ATTR_HYDROPHOBIC) && s < prm->s_hphob) kind |= 1u << ARP_HydrophobicContact;
+    if ((ax & ay & ARP_ATTR_HYDROPHOBIC) && s < prm.s_hphob) kind |= 1u << ARP_HydrophobicContact;
     return kind;
 }
 
 // ---------------------------------------------------------------------------------------------- pair search
-// One wave per home cell.  Half shell: the home cell against itself (slot order breaks the tie), its +x neighbour,
-// the three cells of row (y+1, z) and the nine cells of layer z+1 -- five contiguous slot ranges because cells are
-// x-major.  Every unordered pair is therefore tested exactly once; the reference's ordered pair (x in L, y in R)
-// is recovered by candidate(), of which at most one orientation can hold (complex.rs:108-130).
+// One wave-task = 64 consecutive slots of the cell-sorted order; lane = home atom (kept in registers).
+// Half shell: the rest of the home cell and its +x neighbour, the three cells of row (y+1, z) and the nine cells of
+// layer z+1 -- five contiguous slot windows per lane because cells are x-major.  Every unordered pair is tested
+// exactly once; the reference's ordered pair (x in L, y in R) is recovered by candidate(), of which at most one
+// orientation can hold (complex.rs:108-130).
 //
-// Phase 1 (all lanes): flat (home, neighbour) enumeration, f32 distance prefilter, survivors are compacted into an
-// LDS queue with a wavefront ballot + prefix count.  Phase 2 (full waves of 64 survivors): exact f64 decision,
+// For each of the five window kinds the wave stages the covering slot interval through a private LDS buffer in
+// chunks (coalesced 16-byte loads), then every lane walks the part of ITS window inside the chunk with one
+// ds_read_b128 per test.  Phase 1 = f32 distance prefilter; survivors are compacted into an LDS queue with a
+// wavefront ballot + prefix count.  Phase 2 runs on full waves of 64 survivors: exact f64 decision, pair filter,
 // classification, and either a count (COUNT pass) or a coalesced 16-byte-per-lane store (FILL pass).
 constexpr int kWavesPerBlock = 4;
 constexpr int kQueue = 128;
-constexpr uint32_t kPairBlocks = 256 * 8;  // persistent: 8 blocks of 4 waves per CU, cells dealt round-robin
+constexpr uint32_t kChunk = 128;           // neighbour records per staged chunk
+constexpr uint32_t kBlock = 16;            // prefilter tests per lane between two compaction steps
+constexpr uint32_t kPairBlocks = 256 * 8;  // persistent grid: tasks are dealt round-robin to the waves
+
+// Per-wave LDS working set (11.5 KB): everything both phases touch per test / per survivor lives here, so the inner
+// loops issue no global gathers (a 64-line gather costs the CU's single vector-L1 path ~64 cycles per instruction).
+struct WaveLds {
+    float4 nrec[kChunk + kBlock];  // f32 prefilter records of the staged neighbour chunk (+ kBlock: over-reads stay in bounds)
+    Fat nfat[kChunk];              // exact records of the same chunk
+    Fat hfat[64];                  // exact records of the 64 home atoms of the task
+    uint16_t queue[kQueue];        // survivors: home lane << 8 | offset in chunk
+};
 
 template <bool FILL>
-DEVFN uint32_t process_batch(const DevAtoms &in, const DevParams *prm, const Sorted &so, uint2 ent, bool active,
-                             unsigned long long base, uint32_t emitted, arp_pair *out, unsigned long long capacity,
-                             unsigned long long *result) {
+DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, const WaveLds &w, uint32_t ent, bool active,
+                             uint32_t home_slot0, uint32_t chunk_slot0, unsigned long long base, uint32_t emitted, arp_pair *out,
+                             unsigned long long capacity, unsigned long long *result) {
     bool valid = false, swap = false;
     double s = 0.0;
-    uint4 ma = make_uint4(0, 0, 0, 0), mb = ma;
-    double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
+    Fat a, b;
+    const uint32_t hl = ent >> 8, no = ent & 0xFFu;
     if (active) {
-        pa[0] = so.x[ent.x]; pa[1] = so.y[ent.x]; pa[2] = so.z[ent.x];
-        pb[0] = so.x[ent.y]; pb[1] = so.y[ent.y]; pb[2] = so.z[ent.y];
-        s = sq_dist(pa[0], pa[1], pa[2], pb[0], pb[1], pb[2]);
-        if (s <= prm->r2) {  // rstar: inclusive
-            ma = so.meta[ent.x]; mb = so.meta[ent.y];
-            if (candidate(ma, mb)) valid = true;
-            else if (candidate(mb, ma)) { valid = true; swap = true; }
+        a = w.hfat[hl]; b = w.nfat[no];
+        s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
+        if (s <= prm.r2) {  // rstar: inclusive
+            if (candidate(a, b)) valid = true;
+            else if (candidate(b, a)) { valid = true; swap = true; }
         }
     }
     unsigned long long vm = __ballot(valid);
     if (FILL) {
         if (valid) {
-            uint32_t kind = swap ? classify(in, prm, s, mb, ma, pb, pa, result) : classify(in, prm, s, ma, mb, pa, pb, result);
+            const uint32_t sa = home_slot0 + hl, sb = chunk_slot0 + no;
+            uint32_t kind = swap ? classify(in, prm, so.hinfo, s, b, sb, a, sa, result) : classify(in, prm, so.hinfo, s, a, sa, b, sb, result);
             unsigned long long pos = base + emitted + mbcnt(vm);
             if (pos < capacity) {
-                arp_pair r;
-                r.i = swap ? mb.w : ma.w; r.j = swap ? ma.w : mb.w;
-                r.dist = (float)sqrt(s);
-                r.kind = kind;
-                out[pos] = r;
+                uint4 r;
+                r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
+                r.z = __float_as_uint((float)sqrt(s));
+                r.w = kind;
+                reinterpret_cast<uint4 *>(out)[pos] = r;
             }
         }
     }
     return (uint32_t)__popcll(vm);
 }
 
+// mask = 2 * mask + (d2 <= r2f): one compare and one add-with-carry per prefilter test
+DEVFN void push_pass(uint32_t &mask, float d2, float r2f) {
+    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2f) : "vcc");
+}
+
 template <bool FILL>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *prm,
-                                                               const uint32_t *cell_start, Sorted so, uint32_t *task_count,
-                                                               const unsigned long long *task_base, arp_pair *out,
-                                                               unsigned long long capacity, unsigned long long *result) {
-    __shared__ uint2 queue[kWavesPerBlock][kQueue];
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
+                                                               Sorted so, uint32_t *task_count, const unsigned long long *task_base,
+                                                               arp_pair *out, unsigned long long capacity, unsigned long long *result) {
+    __shared__ LdsParams prm;
+    __shared__ WaveLds wl[kWavesPerBlock];
+    {   // decision bounds -> LDS once per block
+        const double *src = dprm->s_clash;
+        double *dst = prm.s_clash;
+        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
+        if (threadIdx.x == 0) { prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob; }
+        __syncthreads();
+    }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, ncells = gp->ncells;
-    const float r2f = prm->r2f;
-    uint2 *q = queue[wave];
+    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
+    const float r2f = dprm->r2f;
+    WaveLds &w = wl[wave];
 #pragma unroll 1
-    for (uint32_t c = blockIdx.x * kWavesPerBlock + wave; c < ncells; c += gridDim.x * kWavesPerBlock) {
-    const uint32_t hs = cell_start[c], he = cell_start[c + 1], nh = he - hs;
-    if (nh == 0) { if (!FILL && lane == 0) task_count[c] = 0; continue; }
-    const uint32_t cx = c % nx, cy = (c / nx) % ny, cz = c / (nx * ny);
-    const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
-    // five slot ranges
-    uint32_t rs[5], re[5];
-    {
-        uint32_t row = (cz * ny + cy) * nx;
-        rs[0] = hs; re[0] = cell_start[row + xhi + 1];
-        int k = 1;
-        for (int dz = 0; dz <= 1; dz++)
-            for (int dy = (dz ? -1 : 1); dy <= 1; dy++, k++) {
-                int yy = (int)cy + dy; uint32_t zz = cz + dz;
-                if (yy < 0 || yy >= (int)ny || zz >= nzt) { rs[k] = re[k] = 0; continue; }
-                uint32_t r = (zz * ny + (uint32_t)yy) * nx;
-                rs[k] = cell_start[r + xlo]; re[k] = cell_start[r + xhi + 1];
-            }
-    }
-    const unsigned long long base = FILL ? task_base[c] : 0ull;
-    uint32_t qlen = 0, emitted = 0;
-    const uint32_t dh = 64u % nh, dn = 64u / nh;
-#pragma unroll 1
-    for (int k = 0; k < 5; k++) {
-        const uint32_t ns = rs[k], nn = re[k] - rs[k];
-        if (nn == 0) continue;
-        uint32_t hoff = lane % nh, noff = lane / nh;
-        const unsigned long long total = (unsigned long long)nh * nn;
-#pragma unroll 1
-        for (unsigned long long t0 = 0; t0 < total; t0 += 64) {
-            bool pass = false;
-            uint32_t h = hs + hoff, n = ns + noff;
-            if (noff < nn) {
-                float4 a = so.rec[h], b = so.rec[n];
-                float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
-                float d2 = dx * dx + dy * dy + dz * dz;
-                pass = (d2 <= r2f) && (k != 0 || n > h);
-            }
-            unsigned long long m = __ballot(pass);
-            if (pass) q[qlen + mbcnt(m)] = make_uint2(h, n);
-            qlen += (uint32_t)__popcll(m);
-            if (qlen >= 64) {
-                qlen -= 64;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lanes read entries other lanes wrote
-                uint2 ent = q[qlen + lane];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                emitted += process_batch<FILL>(in, prm, so, ent, true, base, emitted, out, capacity, result);
-            }
-            hoff += dh; noff += dn;
-            if (hoff >= nh) { hoff -= nh; noff++; }
+    for (uint32_t t = blockIdx.x * kWavesPerBlock + wave; t < n_tasks; t += gridDim.x * kWavesPerBlock) {
+        const uint32_t a0 = t * 64u, a = a0 + lane;  // this lane's home slot
+        const bool have = a < n_heavy;
+        float4 home = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t cx = 0, cy = 0, cz = 0;
+        if (have) {
+            home = so.rec[a];
+            uint32_t c = __float_as_uint(home.w);
+            cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
         }
+        wave_lds_fence();  // previous task's batches are done with hfat
+        {   // exact records of the 64 home atoms -> LDS (the arrays are padded by 64 entries)
+            const uint4 *src = reinterpret_cast<const uint4 *>(so.fat + a0);
+            uint4 *dst = reinterpret_cast<uint4 *>(w.hfat);
+            for (uint32_t p = lane; p < 64u * 3u; p += 64u) dst[p] = src[p];
+        }
+        const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
+        const unsigned long long base = FILL ? task_base[t] : 0ull;
+        uint32_t emitted = 0;
+#pragma unroll 1
+        for (int k = 0; k < 5; k++) {
+            // this lane's slot window for window kind k
+            uint32_t lo = 0, hi = 0;
+            if (have) {
+                if (k == 0) {
+                    lo = a + 1; hi = cell_start[(cz * ny + cy) * nx + xhi + 1];
+                } else {
+                    const int dy = (k == 1) ? 1 : (k - 3);
+                    const uint32_t zz = cz + (k == 1 ? 0u : 1u);
+                    const int yy = (int)cy + dy;
+                    if (yy >= 0 && yy < (int)ny && zz < nzt) {
+                        const uint32_t r = (zz * ny + (uint32_t)yy) * nx;
+                        lo = cell_start[r + xlo]; hi = cell_start[r + xhi + 1];
+                    }
+                }
+            }
+            const bool nonempty = lo < hi;
+            const uint32_t L = wave_min_u32(nonempty ? lo : 0xFFFFFFFFu), H = wave_max_u32(nonempty ? hi : 0u);
+            if (L >= H) continue;
+#pragma unroll 1
+            for (uint32_t cs = L; cs < H; cs += kChunk) {
+                const uint32_t ce = min(cs + kChunk, H);
+                const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
+                const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
+                if (!__any(len != 0u)) continue;
+                wave_lds_fence();  // previous chunk fully consumed (its queue was drained)
+                {
+                    const uint32_t cnt = ce - cs;
+                    for (uint32_t p = lane; p < cnt; p += 64u) w.nrec[p] = so.rec[cs + p];
+                    const uint4 *src = reinterpret_cast<const uint4 *>(so.fat + cs);
+                    uint4 *dst = reinterpret_cast<uint4 *>(w.nfat);
+                    for (uint32_t p = lane; p < cnt * 3u; p += 64u) dst[p] = src[p];
+                }
+                wave_lds_fence();
+                const uint32_t off = len ? j0 - cs : 0u;
+                uint32_t qlen = 0;  // wave-uniform
+#pragma unroll 1
+                for (uint32_t it0 = 0; __any(it0 < len); it0 += kBlock) {
+                    // Phase 1: kBlock prefilter tests per lane, results pushed into a per-lane bit mask (test u -> bit kBlock-1-u).
+                    // Lanes whose window is exhausted read slots 0..kBlock-1 (any staged data will do: their bits are dropped).
+                    const uint32_t wbase = it0 < len ? off + it0 : 0u;
+                    const float4 *win = w.nrec + wbase;
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < kBlock; ++u) {
+                        const float4 r = win[u];
+                        const float dx = r.x - home.x, dy = r.y - home.y, dz = r.z - home.z;
+                        push_pass(mask, __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz)), r2f);
+                    }
+                    const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
+                    if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);
+                    // Compaction: one round per surviving test of the busiest lane; every round appends <= 64 entries
+                    while (__any(mask != 0u)) {
+                        const bool has = mask != 0u;
+                        const uint32_t bit = 31u - (uint32_t)__clz((int)mask);
+                        const unsigned long long m = __ballot(has);
+                        if (has) {
+                            w.queue[qlen + mbcnt(m)] = (uint16_t)((lane << 8) | (wbase + (kBlock - 1u - bit)));
+                            mask &= ~(1u << bit);
+                        }
+                        qlen = __builtin_amdgcn_readfirstlane(qlen + (uint32_t)__popcll(m));
+                        if (qlen >= 64) {
+                            qlen -= 64;
+                            wave_lds_fence();  // lanes read entries other lanes wrote
+                            const uint32_t ent = w.queue[qlen + lane];
+                            wave_lds_fence();
+                            emitted += process_batch<FILL>(in, prm, so, w, ent, true, a0, cs, base, emitted, out, capacity, result);
+                        }
+                    }
+                }
+                // Drain: queue entries are chunk-relative, and the per-task COUNT/FILL bookkeeping keeps the output order
+                // a function of the input only.
+                if (qlen) {
+                    const bool act = lane < qlen;
+                    wave_lds_fence();
+                    const uint32_t ent = act ? w.queue[lane] : 0u;
+                    wave_lds_fence();
+                    emitted += process_batch<FILL>(in, prm, so, w, ent, act, a0, cs, base, emitted, out, capacity, result);
+                }
+            }
+        }
+        if (!FILL && lane == 0) task_count[t] = emitted;
     }
-    if (qlen) {
-        bool act = lane < qlen;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        uint2 ent = act ? q[lane] : make_uint2(0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        emitted += process_batch<FILL>(in, prm, so, ent, act, base, emitted, out, capacity, result);
-    }
-    if (!FILL && lane == 0) task_count[c] = emitted;
-    }  // cell loop
 }
 
 __global__ void k_finish(const GridParams *g, const unsigned long long *task_base, unsigned long long *result, unsigned long long capacity,
                          int have_out) {
     if (threadIdx.x | blockIdx.x) return;
-    unsigned long long total = task_base[g->ncells];
+    unsigned long long total = task_base[g->n_tasks];
     result[0] = total;
     if (have_out && total > capacity) result[1] |= 1ull;
     if (g->bad) result[1] |= 4ull;
@@ -479,6 +593,12 @@ static void launch_scan(const uint32_t *in, const uint32_t *n_ptr, TOut *tmp, TO
     hipLaunchKernelGGL(k_scan_apply<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, (const TOut *)tmp, out);
 }
 
+static uint32_t pair_blocks_for(uint32_t n) {
+    uint32_t tasks = (n + 63u) / 64u;
+    uint32_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    return blocks < 1 ? 1 : (blocks > kPairBlocks ? kPairBlocks : blocks);
+}
+
 void launch_pipeline(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, bool fill,
                      Profiler *prof, double cutoff) {
     const uint32_t n = in.n;
@@ -488,48 +608,41 @@ void launch_pipeline(const DevAtoms &in, const Workspace &ws, arp_pair *out, uns
     if (prof) prof->n = 0;
     P0("grid_bounds");
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, ws.bounds, ws.result);
-    if (n) hipLaunchKernelGGL(k_bounds, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, in, ws.bounds);
+    if (n) hipLaunchKernelGGL(k_bounds, dim3(nb < 256 ? nb : 256), dim3(256), 0, st, in, ws.bounds);
     hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, (const Bounds *)ws.bounds, ws.grid, ws.params, cutoff, ws.ncells_cap);
     P1();
     P0("grid_count");
-    hipLaunchKernelGGL(k_zero_cells, dim3(1024), dim3(256), 0, st, (const GridParams *)ws.grid, ws.cell_count, ws.cell_fill);
-    if (n) hipLaunchKernelGGL(k_cellid, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.cell_count);
+    hipLaunchKernelGGL(k_zero_cells, dim3(1024), dim3(256), 0, st, (const GridParams *)ws.grid, ws.cell_count);
+    if (n) hipLaunchKernelGGL(k_cellid, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
     P1();
     P0("grid_scan");
     launch_scan<uint32_t>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, st);
     P1();
     P0("grid_sort");
     if (n) {
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, n, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.cell_start,
-                           ws.cell_fill, ws.perm, ws.slot_cell);
-        hipLaunchKernelGGL(k_gather, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, (const uint32_t *)ws.cell_start,
-                           (const uint32_t *)ws.perm, (const uint32_t *)ws.slot_cell, ws.sorted);
+        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, n, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.rank_of_atom,
+                           (const uint32_t *)ws.cell_start, ws.perm, ws.slot_cell);
     }
+    hipLaunchKernelGGL(k_gather, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.perm,
+                       (const uint32_t *)ws.slot_cell, ws.sorted);
     P1();
-    const uint32_t pair_blocks = kPairBlocks;
+    const uint32_t pair_blocks = pair_blocks_for(n);
     P0("pairs_count");
     hipLaunchKernelGGL(k_pairs<false>, dim3(pair_blocks), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
                        (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
                        (const unsigned long long *)ws.task_base, (arp_pair *)nullptr, 0ull, ws.result);
     P1();
     P0("pairs_scan");
-    launch_scan<unsigned long long>(ws.task_count, &ws.grid->ncells, ws.scan_tmp64, ws.task_base, st);
+    launch_scan<unsigned long long>(ws.task_count, &ws.grid->n_tasks, ws.scan_tmp64, ws.task_base, st);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, (const GridParams *)ws.grid, (const unsigned long long *)ws.task_base, ws.result,
                        capacity, fill ? 1 : 0);
     P1();
-    if (fill) {
-        P0("pairs_fill");
-        hipLaunchKernelGGL(k_pairs<true>, dim3(pair_blocks), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
-                           (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
-                           (const unsigned long long *)ws.task_base, out, capacity, ws.result);
-        P1();
-    }
+    if (fill) launch_fill_only(in, ws, out, capacity, st, prof);
 }
 
 void launch_fill_only(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
-    const uint32_t pair_blocks = kPairBlocks;
     if (prof) prof->begin("pairs_fill", st);
-    hipLaunchKernelGGL(k_pairs<true>, dim3(pair_blocks), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+    hipLaunchKernelGGL(k_pairs<true>, dim3(pair_blocks_for(in.n)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
                        (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
                        (const unsigned long long *)ws.task_base, out, capacity, ws.result);
     if (prof) prof->end(st);

@@ -125,7 +125,8 @@ int32_t arp_element_class(const char *symbol); /* class index used by arp_defaul
 /* ---- context ---- */
 arp_status arp_context_create(int32_t device, arp_context **out);
 void arp_context_destroy(arp_context *ctx);
-/* Launch on a caller-owned HIP stream (hipStream_t passed as void*; NULL = the context's own stream). */
+/* Launch on a caller-owned HIP stream (hipStream_t passed as void*; NULL = the legacy default stream).  A new context
+ * starts on a private non-blocking stream of its own. */
 arp_status arp_context_set_stream(arp_context *ctx, void *hip_stream);
 arp_status arp_context_synchronize(arp_context *ctx);
 
