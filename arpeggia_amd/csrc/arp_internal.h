@@ -82,7 +82,10 @@ struct Workspace {
     unsigned long long *task_base;  // n/64 + 2
     uint32_t *scan_tmp;       // block sums (1024 + 1)
     unsigned long long *scan_tmp64;
-    unsigned long long *result;  // [0] = total pairs, [1] = flags
+    unsigned long long *result;  // [0] = total pairs, [1] = flags, [2] = emit allocator head (64-record units)
+    ulonglong2 *hole_list;    // emit mode: one (start, length) per block
+    arp_pair *scratch;        // emit mode: home of positions >= the caller's capacity until k_fixup has closed the holes
+    unsigned long long scratch_cap;
     uint32_t ncells_cap;
     uint32_t n_cap;
 };
@@ -98,10 +101,11 @@ struct Profiler {
     void end(hipStream_t st);
 };
 
-// Launch wrappers (kernels.hip).  All asynchronous on `st`.
-void launch_pipeline(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
-                     bool fill, Profiler *prof, double cutoff);
-void launch_fill_only(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st,
-                      Profiler *prof);
+// Launch wrappers (kernels.hip / pairs.inl).  All asynchronous on `st`.
+void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff);
+void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out);
+void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
+void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
+unsigned long long emit_scratch_records();
 
 }  // namespace arp

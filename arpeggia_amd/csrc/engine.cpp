@@ -136,7 +136,8 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.perm, cap); A(w.slot_cell, cap);
     A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.hinfo, cap);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
-    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 2);
+    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);
+    A(w.hole_list, 1024); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
 #undef A
     w.n_cap = (uint32_t)cap;
     w.ncells_cap = (uint32_t)ccap;
@@ -293,7 +294,16 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
     DevAtoms d{};
     if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
-    launch_pipeline(d, ctx->ws, out, capacity, ctx->stream, /*fill=*/true, ctx->prof.enabled ? &ctx->prof : nullptr, params->dist_cutoff);
+    Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff);
+    if (!out || capacity == 0) {
+        launch_count(d, ctx->ws, ctx->stream, prof, 0, true);  // size query: reports ARP_ERR_CAPACITY + the count
+    } else if (params->flags & ARP_FLAG_DETERMINISTIC) {
+        launch_count(d, ctx->ws, ctx->stream, prof, capacity, true);
+        launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof);
+    } else {
+        launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     ctx->last_capacity = capacity;
@@ -329,8 +339,9 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
-    // count pass -> exact output size -> fill pass
-    launch_pipeline(d, ctx->ws, nullptr, 0, ctx->stream, /*fill=*/false, prof, params->dist_cutoff);
+    // count pass -> exact output size -> ordered fill or single-pass emit
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff);
+    launch_count(d, ctx->ws, ctx->stream, prof, 0, false);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -339,7 +350,8 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     if (total == 0) return ARP_OK;
     arp_pair *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
-    launch_fill_only(d, ctx->ws, dev, total, ctx->stream, prof);
+    if (params->flags & ARP_FLAG_DETERMINISTIC) launch_fill_ordered(d, ctx->ws, dev, total, ctx->stream, prof);
+    else launch_emit(d, ctx->ws, dev, total, ctx->stream, prof);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -7,6 +7,8 @@
 // (src/contacts/complex.rs:189-299) with a uniform-grid cell list and a count/scan/fill pair emitter whose
 // output order is deterministic.  Decisions are made in f64 with the reference's operation order and no FMA
 // contraction (this file is compiled with -ffp-contract=off); an f32 test with a proven margin only prefilters.
+#include <cstdlib>
+
 #include "arp_internal.h"
 
 namespace arp {
@@ -45,7 +47,7 @@ constexpr uint32_t kAttrResHasH = 0x80000000u;  // internal: the atom's residue 
 // ---------------------------------------------------------------------------------------------- grid build
 __global__ void k_init(Bounds *b, unsigned long long *result) {
     if (threadIdx.x < 3) { b->mn[threadIdx.x] = ~0ull; b->mx[threadIdx.x] = 0ull; }
-    if (threadIdx.x == 0) { b->n_models = 0; b->bad = 0; result[0] = 0; result[1] = 0; }
+    if (threadIdx.x == 0) { b->n_models = 0; b->bad = 0; result[0] = 0; result[1] = 0; result[2] = 0; }
 }
 
 // Bounding box of the heavy atoms: registers -> wave shuffles -> LDS -> one atomic set per block (<= 256 blocks).
@@ -244,7 +246,11 @@ __global__ __launch_bounds__(256) void k_gather(DevAtoms in, GridParams *gp, con
     if (p >= n_heavy) return;
     uint32_t c = slot_cell[p], i = perm[p];
     uint32_t s = cell_start[c], e = cell_start[c + 1], rank = 0;
-    for (uint32_t q = s; q < e; q++) rank += (perm[q] < i) ? 1u : 0u;
+    for (uint32_t q = s; q < e; q += 4) {  // four independent loads per trip: the loop is latency-bound otherwise
+        const uint32_t u0 = perm[q], u1 = (q + 1 < e) ? perm[q + 1] : 0xFFFFFFFFu, u2 = (q + 2 < e) ? perm[q + 2] : 0xFFFFFFFFu,
+                       u3 = (q + 3 < e) ? perm[q + 3] : 0xFFFFFFFFu;
+        rank += (u0 < i) + (u1 < i) + (u2 < i) + (u3 < i);
+    }
     uint32_t d = s + rank;
     double x = in.x[i], y = in.y[i], z = in.z[i];
     so.rec[d] = make_float4((float)(x - gp->ox), (float)(y - gp->oy), (float)(z - gp->oz), __uint_as_float(c));
@@ -374,278 +380,7 @@ DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *h
     return kind;
 }
 
-// ---------------------------------------------------------------------------------------------- pair search
-// One wave-task = 64 consecutive slots of the cell-sorted order; lane = home atom (kept in registers).
-// Half shell: the rest of the home cell and its +x neighbour, the three cells of row (y+1, z) and the nine cells of
-// layer z+1 -- five contiguous slot windows per lane because cells are x-major.  Every unordered pair is tested
-// exactly once; the reference's ordered pair (x in L, y in R) is recovered by candidate(), of which at most one
-// orientation can hold (complex.rs:108-130).
-//
-// For each of the five window kinds the wave stages the covering slot interval through a private LDS buffer in
-// chunks (coalesced 16-byte loads), then every lane walks the part of ITS window inside the chunk with one
-// ds_read_b128 per test.  Phase 1 = f32 distance prefilter; survivors are compacted into an LDS queue with a
-// wavefront ballot + prefix count.  Phase 2 runs on full waves of 64 survivors: exact f64 decision, pair filter,
-// classification, and either a count (COUNT pass) or a coalesced 16-byte-per-lane store (FILL pass).
-constexpr int kWavesPerBlock = 4;
-constexpr int kQueue = 128;
-constexpr uint32_t kChunk = 128;           // neighbour records per staged chunk
-constexpr uint32_t kBlock = 16;            // prefilter tests per lane between two compaction steps
-constexpr uint32_t kPairBlocks = 256 * 8;  // persistent grid: tasks are dealt round-robin to the waves
-
-// Per-wave LDS working set (11.5 KB): everything both phases touch per test / per survivor lives here, so the inner
-// loops issue no global gathers (a 64-line gather costs the CU's single vector-L1 path ~64 cycles per instruction).
-struct WaveLds {
-    float4 nrec[kChunk + kBlock];  // f32 prefilter records of the staged neighbour chunk (+ kBlock: over-reads stay in bounds)
-    Fat nfat[kChunk];              // exact records of the same chunk
-    Fat hfat[64];                  // exact records of the 64 home atoms of the task
-    uint16_t queue[kQueue];        // survivors: home lane << 8 | offset in chunk
-};
-
-template <bool FILL>
-DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, const WaveLds &w, uint32_t ent, bool active,
-                             uint32_t home_slot0, uint32_t chunk_slot0, unsigned long long base, uint32_t emitted, arp_pair *out,
-                             unsigned long long capacity, unsigned long long *result) {
-    bool valid = false, swap = false;
-    double s = 0.0;
-    Fat a, b;
-    const uint32_t hl = ent >> 8, no = ent & 0xFFu;
-    if (active) {
-        a = w.hfat[hl]; b = w.nfat[no];
-        s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
-        if (s <= prm.r2) {  // rstar: inclusive
-            if (candidate(a, b)) valid = true;
-            else if (candidate(b, a)) { valid = true; swap = true; }
-        }
-    }
-    unsigned long long vm = __ballot(valid);
-    if (FILL) {
-        if (valid) {
-            const uint32_t sa = home_slot0 + hl, sb = chunk_slot0 + no;
-            uint32_t kind = swap ? classify(in, prm, so.hinfo, s, b, sb, a, sa, result) : classify(in, prm, so.hinfo, s, a, sa, b, sb, result);
-            unsigned long long pos = base + emitted + mbcnt(vm);
-            if (pos < capacity) {
-                uint4 r;
-                r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
-                r.z = __float_as_uint((float)sqrt(s));
-                r.w = kind;
-                reinterpret_cast<uint4 *>(out)[pos] = r;
-            }
-        }
-    }
-    return (uint32_t)__popcll(vm);
-}
-
-// mask = 2 * mask + (d2 <= r2f): one compare and one add-with-carry per prefilter test
-DEVFN void push_pass(uint32_t &mask, float d2, float r2f) {
-    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2f) : "vcc");
-}
-
-template <bool FILL>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
-                                                               Sorted so, uint32_t *task_count, const unsigned long long *task_base,
-                                                               arp_pair *out, unsigned long long capacity, unsigned long long *result) {
-    __shared__ LdsParams prm;
-    __shared__ WaveLds wl[kWavesPerBlock];
-    {   // decision bounds -> LDS once per block
-        const double *src = dprm->s_clash;
-        double *dst = prm.s_clash;
-        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
-        if (threadIdx.x == 0) { prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob; }
-        __syncthreads();
-    }
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
-    const float r2f = dprm->r2f;
-    WaveLds &w = wl[wave];
-#pragma unroll 1
-    for (uint32_t t = blockIdx.x * kWavesPerBlock + wave; t < n_tasks; t += gridDim.x * kWavesPerBlock) {
-        const uint32_t a0 = t * 64u, a = a0 + lane;  // this lane's home slot
-        const bool have = a < n_heavy;
-        float4 home = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t cx = 0, cy = 0, cz = 0;
-        if (have) {
-            home = so.rec[a];
-            uint32_t c = __float_as_uint(home.w);
-            cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
-        }
-        wave_lds_fence();  // previous task's batches are done with hfat
-        {   // exact records of the 64 home atoms -> LDS (the arrays are padded by 64 entries)
-            const uint4 *src = reinterpret_cast<const uint4 *>(so.fat + a0);
-            uint4 *dst = reinterpret_cast<uint4 *>(w.hfat);
-            for (uint32_t p = lane; p < 64u * 3u; p += 64u) dst[p] = src[p];
-        }
-        const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
-        const unsigned long long base = FILL ? task_base[t] : 0ull;
-        uint32_t emitted = 0;
-#pragma unroll 1
-        for (int k = 0; k < 5; k++) {
-            // this lane's slot window for window kind k
-            uint32_t lo = 0, hi = 0;
-            if (have) {
-                if (k == 0) {
-                    lo = a + 1; hi = cell_start[(cz * ny + cy) * nx + xhi + 1];
-                } else {
-                    const int dy = (k == 1) ? 1 : (k - 3);
-                    const uint32_t zz = cz + (k == 1 ? 0u : 1u);
-                    const int yy = (int)cy + dy;
-                    if (yy >= 0 && yy < (int)ny && zz < nzt) {
-                        const uint32_t r = (zz * ny + (uint32_t)yy) * nx;
-                        lo = cell_start[r + xlo]; hi = cell_start[r + xhi + 1];
-                    }
-                }
-            }
-            const bool nonempty = lo < hi;
-            const uint32_t L = wave_min_u32(nonempty ? lo : 0xFFFFFFFFu), H = wave_max_u32(nonempty ? hi : 0u);
-            if (L >= H) continue;
-#pragma unroll 1
-            for (uint32_t cs = L; cs < H; cs += kChunk) {
-                const uint32_t ce = min(cs + kChunk, H);
-                const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
-                const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
-                if (!__any(len != 0u)) continue;
-                wave_lds_fence();  // previous chunk fully consumed (its queue was drained)
-                {
-                    const uint32_t cnt = ce - cs;
-                    for (uint32_t p = lane; p < cnt; p += 64u) w.nrec[p] = so.rec[cs + p];
-                    const uint4 *src = reinterpret_cast<const uint4 *>(so.fat + cs);
-                    uint4 *dst = reinterpret_cast<uint4 *>(w.nfat);
-                    for (uint32_t p = lane; p < cnt * 3u; p += 64u) dst[p] = src[p];
-                }
-                wave_lds_fence();
-                const uint32_t off = len ? j0 - cs : 0u;
-                uint32_t qlen = 0;  // wave-uniform
-#pragma unroll 1
-                for (uint32_t it0 = 0; __any(it0 < len); it0 += kBlock) {
-                    // Phase 1: kBlock prefilter tests per lane, results pushed into a per-lane bit mask (test u -> bit kBlock-1-u).
-                    // Lanes whose window is exhausted read slots 0..kBlock-1 (any staged data will do: their bits are dropped).
-                    const uint32_t wbase = it0 < len ? off + it0 : 0u;
-                    const float4 *win = w.nrec + wbase;
-                    uint32_t mask = 0;
-#pragma unroll
-                    for (uint32_t u = 0; u < kBlock; ++u) {
-                        const float4 r = win[u];
-                        const float dx = r.x - home.x, dy = r.y - home.y, dz = r.z - home.z;
-                        push_pass(mask, __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz)), r2f);
-                    }
-                    const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
-                    if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);
-                    // Compaction: one round per surviving test of the busiest lane; every round appends <= 64 entries
-                    while (__any(mask != 0u)) {
-                        const bool has = mask != 0u;
-                        const uint32_t bit = 31u - (uint32_t)__clz((int)mask);
-                        const unsigned long long m = __ballot(has);
-                        if (has) {
-                            w.queue[qlen + mbcnt(m)] = (uint16_t)((lane << 8) | (wbase + (kBlock - 1u - bit)));
-                            mask &= ~(1u << bit);
-                        }
-                        qlen = __builtin_amdgcn_readfirstlane(qlen + (uint32_t)__popcll(m));
-                        if (qlen >= 64) {
-                            qlen -= 64;
-                            wave_lds_fence();  // lanes read entries other lanes wrote
-                            const uint32_t ent = w.queue[qlen + lane];
-                            wave_lds_fence();
-                            emitted += process_batch<FILL>(in, prm, so, w, ent, true, a0, cs, base, emitted, out, capacity, result);
-                        }
-                    }
-                }
-                // Drain: queue entries are chunk-relative, and the per-task COUNT/FILL bookkeeping keeps the output order
-                // a function of the input only.
-                if (qlen) {
-                    const bool act = lane < qlen;
-                    wave_lds_fence();
-                    const uint32_t ent = act ? w.queue[lane] : 0u;
-                    wave_lds_fence();
-                    emitted += process_batch<FILL>(in, prm, so, w, ent, act, a0, cs, base, emitted, out, capacity, result);
-                }
-            }
-        }
-        if (!FILL && lane == 0) task_count[t] = emitted;
-    }
-}
-
-__global__ void k_finish(const GridParams *g, const unsigned long long *task_base, unsigned long long *result, unsigned long long capacity,
-                         int have_out) {
-    if (threadIdx.x | blockIdx.x) return;
-    unsigned long long total = task_base[g->n_tasks];
-    result[0] = total;
-    if (have_out && total > capacity) result[1] |= 1ull;
-    if (g->bad) result[1] |= 4ull;
-}
-
-// ---------------------------------------------------------------------------------------------- profiler + launch
-void Profiler::begin(const char *name, hipStream_t st) {
-    if (!enabled) return;
-    if (!created) { for (int k = 0; k < kMax; k++) { (void)hipEventCreate(&ev0[k]); (void)hipEventCreate(&ev1[k]); } created = true; }
-    if (n >= kMax) return;
-    names[n] = name;
-    (void)hipEventRecord(ev0[n], st);
-}
-void Profiler::end(hipStream_t st) {
-    if (!enabled || n >= kMax) return;
-    (void)hipEventRecord(ev1[n], st);
-    n++;
-}
-
-template <typename TOut>
-static void launch_scan(const uint32_t *in, const uint32_t *n_ptr, TOut *tmp, TOut *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_reduce<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, tmp);
-    hipLaunchKernelGGL(k_scan_tmp<TOut>, dim3(1), dim3(kScanThreads), 0, st, tmp);
-    hipLaunchKernelGGL(k_scan_apply<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, (const TOut *)tmp, out);
-}
-
-static uint32_t pair_blocks_for(uint32_t n) {
-    uint32_t tasks = (n + 63u) / 64u;
-    uint32_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    return blocks < 1 ? 1 : (blocks > kPairBlocks ? kPairBlocks : blocks);
-}
-
-void launch_pipeline(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, bool fill,
-                     Profiler *prof, double cutoff) {
-    const uint32_t n = in.n;
-    const uint32_t nb = (n + 255) / 256;
-    auto P0 = [&](const char *nm) { if (prof) prof->begin(nm, st); };
-    auto P1 = [&]() { if (prof) prof->end(st); };
-    if (prof) prof->n = 0;
-    P0("grid_bounds");
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, ws.bounds, ws.result);
-    if (n) hipLaunchKernelGGL(k_bounds, dim3(nb < 256 ? nb : 256), dim3(256), 0, st, in, ws.bounds);
-    hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, (const Bounds *)ws.bounds, ws.grid, ws.params, cutoff, ws.ncells_cap);
-    P1();
-    P0("grid_count");
-    hipLaunchKernelGGL(k_zero_cells, dim3(1024), dim3(256), 0, st, (const GridParams *)ws.grid, ws.cell_count);
-    if (n) hipLaunchKernelGGL(k_cellid, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
-    P1();
-    P0("grid_scan");
-    launch_scan<uint32_t>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, st);
-    P1();
-    P0("grid_sort");
-    if (n) {
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, n, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.rank_of_atom,
-                           (const uint32_t *)ws.cell_start, ws.perm, ws.slot_cell);
-    }
-    hipLaunchKernelGGL(k_gather, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.perm,
-                       (const uint32_t *)ws.slot_cell, ws.sorted);
-    P1();
-    const uint32_t pair_blocks = pair_blocks_for(n);
-    P0("pairs_count");
-    hipLaunchKernelGGL(k_pairs<false>, dim3(pair_blocks), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
-                       (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
-                       (const unsigned long long *)ws.task_base, (arp_pair *)nullptr, 0ull, ws.result);
-    P1();
-    P0("pairs_scan");
-    launch_scan<unsigned long long>(ws.task_count, &ws.grid->n_tasks, ws.scan_tmp64, ws.task_base, st);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, (const GridParams *)ws.grid, (const unsigned long long *)ws.task_base, ws.result,
-                       capacity, fill ? 1 : 0);
-    P1();
-    if (fill) launch_fill_only(in, ws, out, capacity, st, prof);
-}
-
-void launch_fill_only(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
-    if (prof) prof->begin("pairs_fill", st);
-    hipLaunchKernelGGL(k_pairs<true>, dim3(pair_blocks_for(in.n)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
-                       (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
-                       (const unsigned long long *)ws.task_base, out, capacity, ws.result);
-    if (prof) prof->end(st);
-}
+// ---------------------------------------------------------------------------------------------- pair search + launch
+#include "pairs.inl"
 
 }  // namespace arp

@@ -1,0 +1,488 @@
+// Pair search, classification and emission kernels + the launch sequence.  Included by kernels.hip inside namespace arp.
+//
+// One wave-task = 64 consecutive slots of the cell-sorted order; lane = home atom (kept in registers).
+// Half shell: the rest of the home cell and its +x neighbour, the three cells of row (y+1, z) and the nine cells of
+// layer z+1 -- five contiguous slot windows per lane because cells are x-major.  Every unordered pair is tested
+// exactly once; the reference's ordered pair (x in L, y in R) is recovered by candidate(), of which at most one
+// orientation can hold (complex.rs:108-130).
+//
+// For each of the five window kinds the wave stages the covering slot interval through a private LDS buffer in
+// chunks (coalesced 16-byte loads); every lane then walks the part of ITS window inside the chunk with one
+// ds_read_b128 per test.  Phase 1 = f32 distance prefilter, 16 tests per lane pushed into a bit mask; survivors are
+// compacted into an LDS queue with wavefront ballots.  Phase 2 runs on full waves of 64 survivors: exact f64
+// decision, pair filter, classification.
+//
+// Three modes share that code:
+//   kCountTasks   candidate pairs per wave-task (for the ordered fill, and for sizing an output buffer)
+//   kFillOrdered  writes task t's pairs at the scanned offset of task t: output order is a function of the input only
+//   kEmit         single pass: classified records are compacted per wave and flushed as 64-record units (1 KiB
+//                 coalesced stores) into chunks that a block-level LDS bump allocator carves out of ONE global
+//                 counter (one device atomic per 2048 records).  The few unused chunk tails ("holes", one per
+//                 block) are closed afterwards by k_fixup, which moves the tail of the array into them.
+enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2 };
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kQueue = 128;
+constexpr uint32_t kChunk = 256;            // neighbour records per staged chunk (4 KB)
+constexpr uint32_t kBlock = 16;             // prefilter tests per lane between two compaction steps
+constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
+constexpr uint32_t kEmitBlocks = 256 * 3;   // emit mode: bounds the number of holes (<= 1024, one k_fixup thread each)
+constexpr uint32_t kUnit = 64;              // records per flush = one wave-wide 16-byte store
+constexpr uint32_t kUnitsPerChunk = 32;     // 2048 records per global allocation
+
+template <int MODE>
+struct WaveLds {                                  // per-wave LDS working set
+    float4 nrec[kChunk + kBlock];                 // f32 prefilter records of the staged chunk (+ kBlock: over-reads stay in bounds)
+    uint2 queue[kQueue];                          // phase-1 survivors: (home slot, neighbour slot)
+    uint4 rq[MODE == kEmit ? 2 * kUnit : 1];      // emit mode: classified records waiting for a full unit
+};
+struct BlockLds {
+    unsigned long long alloc_state;               // current chunk: first unit << 32 | units handed out
+    uint32_t left[kWavesPerBlock];
+};
+
+// mask = 2 * mask + (d2 <= r2f): one compare and one add-with-carry per prefilter test
+DEVFN void push_pass(uint32_t &mask, float d2, float r2f) {
+    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2f) : "vcc");
+}
+
+// Blocks b and b+8 share an XCD (and its private L2): give every XCD one contiguous eighth of the task range so that
+// the neighbour windows its waves stage are served from that L2 instead of being re-fetched by all eight.
+DEVFN uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nb) {
+    const uint32_t xcd = bid & 7u, idx = bid >> 3, q = nb >> 3, r = nb & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+}
+
+struct EmitTarget {  // positions >= capacity spill into the engine's scratch so that a buffer of exactly P records suffices
+    arp_pair *out; unsigned long long capacity;
+    arp_pair *scratch; unsigned long long scratch_cap;
+};
+DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned long long *result) {
+    if (pos < tg.capacity) return reinterpret_cast<uint4 *>(tg.out) + pos;
+    const unsigned long long q = pos - tg.capacity;
+    if (q < tg.scratch_cap) return reinterpret_cast<uint4 *>(tg.scratch) + q;
+    atomicOr(&result[1], 1ull);
+    return nullptr;
+}
+
+// Next free 64-record unit.  Called by a whole wave; lane 0 talks to the block's LDS bump allocator and, once per
+// kUnitsPerChunk units, to the global counter.  A wave that finds the chunk exhausted while another wave is already
+// refilling it sleeps until the new chunk is published (the refilling wave only waits for one returning atomic).
+DEVFN uint32_t alloc_unit(BlockLds &bl, unsigned long long *g_head, uint32_t lane) {
+    uint32_t unit = 0;
+    if (lane == 0) {
+        for (;;) {
+            const unsigned long long old = atomicAdd(&bl.alloc_state, 1ull);
+            const uint32_t used = (uint32_t)old, first = (uint32_t)(old >> 32);
+            if (used < kUnitsPerChunk) { unit = first + used; break; }
+            if (used == kUnitsPerChunk) {
+                const unsigned long long nb = atomicAdd(g_head, (unsigned long long)kUnitsPerChunk);
+                __hip_atomic_store(&bl.alloc_state, (nb << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unit = (uint32_t)nb;
+                break;
+            }
+            while ((uint32_t)(__hip_atomic_load(&bl.alloc_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == first)
+                __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(unit);
+}
+
+template <int MODE>
+DEVFN void flush_unit(WaveLds<MODE> &w, BlockLds &bl, uint32_t &rqlen, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
+    rqlen -= kUnit;
+    wave_lds_fence();
+    const uint4 r = w.rq[rqlen + lane];
+    wave_lds_fence();
+    const uint32_t unit = alloc_unit(bl, &result[2], lane);
+    uint4 *d = emit_slot(tg, (unsigned long long)unit * kUnit + lane, result);
+    if (d) *d = r;
+}
+
+// Phase 2 on up to 64 survivors.  Returns the number of valid candidate pairs of the batch.
+template <int MODE>
+DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
+                             unsigned long long base, uint32_t emitted, uint32_t &rqlen, const EmitTarget &tg, unsigned long long *result,
+                             uint32_t lane) {
+    bool valid = false, swap = false;
+    double s = 0.0;
+    Fat a, b;
+    if (active) {
+        a = so.fat[ent.x]; b = so.fat[ent.y];
+        s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
+        if (s <= prm.r2) {  // rstar: inclusive
+            if (candidate(a, b)) valid = true;
+            else if (candidate(b, a)) { valid = true; swap = true; }
+        }
+    }
+    const unsigned long long vm = __ballot(valid);
+    const uint32_t nvalid = (uint32_t)__popcll(vm);
+    if (MODE != kCountTasks) {
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) {
+            r.w = swap ? classify(in, prm, so.hinfo, s, b, ent.y, a, ent.x, result) : classify(in, prm, so.hinfo, s, a, ent.x, b, ent.y, result);
+            r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
+            r.z = __float_as_uint((float)sqrt(s));
+        }
+        if (MODE == kFillOrdered) {
+            const unsigned long long pos = base + emitted + mbcnt(vm);
+            if (valid && pos < tg.capacity) reinterpret_cast<uint4 *>(tg.out)[pos] = r;
+        } else {
+            if (valid) w.rq[rqlen + mbcnt(vm)] = r;
+            rqlen += nvalid;
+            if (rqlen >= kUnit) flush_unit<MODE>(w, bl, rqlen, tg, result, lane);
+        }
+    }
+    return nvalid;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
+                                                               Sorted so, uint32_t *task_count, const unsigned long long *task_base,
+                                                               EmitTarget tg, ulonglong2 *hole_list, unsigned long long *result) {
+    __shared__ LdsParams prm;
+    __shared__ WaveLds<MODE> wl[kWavesPerBlock];
+    __shared__ BlockLds bl;
+    {   // decision bounds -> LDS once per block
+        const double *src = dprm->s_clash;
+        double *dst = prm.s_clash;
+        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
+        if (threadIdx.x == 0) {
+            prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
+            bl.alloc_state = (0xFFFFFFFFull << 32) | kUnitsPerChunk;  // "exhausted": the first allocation fetches a chunk
+        }
+        __syncthreads();
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
+    const float r2f = dprm->r2f;
+    WaveLds<MODE> &w = wl[wave];
+    const uint32_t per_block = (n_tasks + gridDim.x - 1) / gridDim.x;
+    const uint32_t t_begin = min(n_tasks, xcd_contiguous_block(blockIdx.x, gridDim.x) * per_block), t_end = min(n_tasks, t_begin + per_block);
+    uint32_t rqlen = 0;  // emit mode: records waiting in w.rq (wave-uniform)
+    uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); emit mode carries them across tasks
+#pragma unroll 1
+    for (uint32_t t = t_begin + wave; t < t_end; t += kWavesPerBlock) {
+        const uint32_t a = t * 64u + lane;  // this lane's home slot
+        const bool have = a < n_heavy;
+        float4 home = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t cx = 0, cy = 0, cz = 0;
+        if (have) {
+            home = so.rec[a];
+            uint32_t c = __float_as_uint(home.w);
+            cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
+        }
+        const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
+        // all five slot windows of this lane up front: ten independent loads in flight instead of five round trips
+        uint32_t wlo[5] = {0, 0, 0, 0, 0}, whi[5] = {0, 0, 0, 0, 0};
+        if (have) {
+            wlo[0] = a + 1; whi[0] = cell_start[(cz * ny + cy) * nx + xhi + 1];
+#pragma unroll
+            for (int k = 1; k < 5; k++) {
+                const int dy = (k == 1) ? 1 : (k - 3);
+                const uint32_t zz = cz + (k == 1 ? 0u : 1u);
+                const int yy = (int)cy + dy;
+                if (yy >= 0 && yy < (int)ny && zz < nzt) {
+                    const uint32_t r = (zz * ny + (uint32_t)yy) * nx;
+                    wlo[k] = cell_start[r + xlo]; whi[k] = cell_start[r + xhi + 1];
+                }
+            }
+        }
+        const unsigned long long base = (MODE == kFillOrdered) ? task_base[t] : 0ull;
+        uint32_t emitted = 0;
+#pragma unroll 1
+        for (int k = 0; k < 5; k++) {
+            uint32_t lo = wlo[0], hi = whi[0];
+#pragma unroll
+            for (int j = 1; j < 5; j++) if (k == j) { lo = wlo[j]; hi = whi[j]; }
+            const bool nonempty = lo < hi;
+            const uint32_t L = wave_min_u32(nonempty ? lo : 0xFFFFFFFFu), H = wave_max_u32(nonempty ? hi : 0u);
+            if (L >= H) continue;
+#pragma unroll 1
+            for (uint32_t cs = L; cs < H; cs += kChunk) {
+                const uint32_t ce = min(cs + kChunk, H);
+                const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
+                const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
+                if (!__any(len != 0u)) continue;
+                wave_lds_fence();  // previous chunk fully consumed
+                for (uint32_t p = cs + lane; p < ce; p += 64u) w.nrec[p - cs] = so.rec[p];
+                wave_lds_fence();
+                const uint32_t off = len ? j0 - cs : 0u;
+#pragma unroll 1
+                for (uint32_t it0 = 0; __any(it0 < len); it0 += kBlock) {
+                    // Phase 1: kBlock prefilter tests per lane, results pushed into a per-lane bit mask (test u -> bit kBlock-1-u).
+                    // Lanes whose window is exhausted read slots 0..kBlock-1 (any staged data will do: their bits are dropped).
+                    const uint32_t wbase = it0 < len ? off + it0 : 0u;
+                    const float4 *win = w.nrec + wbase;
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < kBlock; ++u) {
+                        const float4 r = win[u];
+                        const float dx = r.x - home.x, dy = r.y - home.y, dz = r.z - home.z;
+                        push_pass(mask, __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz)), r2f);
+                    }
+                    const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
+                    if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);
+                    // Compaction: one round per surviving test of the busiest lane; every round appends <= 64 entries
+                    while (__any(mask != 0u)) {
+                        const bool has = mask != 0u;
+                        const uint32_t bit = 31u - (uint32_t)__clz((int)mask);
+                        const unsigned long long m = __ballot(has);
+                        if (has) {
+                            w.queue[qlen + mbcnt(m)] = make_uint2(a, cs + wbase + (kBlock - 1u - bit));
+                            mask &= ~(1u << bit);
+                        }
+                        qlen = __builtin_amdgcn_readfirstlane(qlen + (uint32_t)__popcll(m));
+                        if (qlen >= 64) {
+                            qlen -= 64;
+                            wave_lds_fence();  // lanes read entries other lanes wrote
+                            const uint2 ent = w.queue[qlen + lane];
+                            wave_lds_fence();
+                            emitted += process_batch<MODE>(in, prm, so, w, bl, ent, true, base, emitted, rqlen, tg, result, lane);
+                        }
+                    }
+                }
+            }
+        }
+        // Survivors left at the task boundary.  The ordered modes keep their bookkeeping per task, so they drain now.
+        if (MODE != kEmit && qlen) {
+            const bool act = lane < qlen;
+            wave_lds_fence();
+            const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
+            wave_lds_fence();
+            emitted += process_batch<MODE>(in, prm, so, w, bl, ent, act, base, emitted, rqlen, tg, result, lane);
+            qlen = 0;
+        }
+        if (MODE == kCountTasks && lane == 0) task_count[t] = emitted;
+    }
+    if (MODE == kEmit) {
+        if (qlen) {
+            const bool act = lane < qlen;
+            wave_lds_fence();
+            const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
+            wave_lds_fence();
+            process_batch<MODE>(in, prm, so, w, bl, ent, act, 0ull, 0u, rqlen, tg, result, lane);
+        }
+        // Block epilogue: merge the < 64 leftover records of the four waves so that the block leaves exactly ONE hole
+        // (the unused tail of its last chunk) behind.
+        if (lane == 0) bl.left[wave] = rqlen;
+        __syncthreads();
+        uint32_t offs[kWavesPerBlock + 1];
+        offs[0] = 0;
+        for (int v = 0; v < kWavesPerBlock; v++) offs[v + 1] = offs[v] + bl.left[v];
+        const uint32_t total = offs[kWavesPerBlock], units = (total + kUnit - 1) / kUnit;
+        auto write_unit = [&](uint32_t uidx) -> uint32_t {
+            const uint32_t unit = alloc_unit(bl, &result[2], lane);
+            const uint32_t g = uidx * kUnit + lane;
+            if (g < total) {
+                const uint32_t sw = (g >= offs[1]) + (g >= offs[2]) + (g >= offs[3]);
+                uint4 *d = emit_slot(tg, (unsigned long long)unit * kUnit + lane, result);
+                if (d) *d = wl[sw].rq[g - offs[sw]];
+            }
+            return unit;
+        };
+        if (units > 1 && wave < units - 1) write_unit(wave);  // full units first ...
+        __syncthreads();
+        if (wave == 0) {                                        // ... the partial one last, so the hole behind it is contiguous
+            unsigned long long hs = 0, hl = 0;
+            if (units >= 1) {
+                const uint32_t unit = write_unit(units - 1);
+                const unsigned long long st = bl.alloc_state;
+                hs = (unsigned long long)unit * kUnit + (total - (units - 1) * kUnit);
+                hl = ((st >> 32) + kUnitsPerChunk) * kUnit - hs;
+            } else {
+                const unsigned long long st = bl.alloc_state;
+                const uint32_t first = (uint32_t)(st >> 32), used = (uint32_t)st;
+                if (first != 0xFFFFFFFFu) { hs = ((unsigned long long)first + used) * kUnit; hl = (unsigned long long)(kUnitsPerChunk - used) * kUnit; }
+            }
+            if (lane == 0) hole_list[blockIdx.x] = make_ulonglong2(hs, hl);
+        }
+    }
+}
+
+__global__ void k_finish(const GridParams *g, const unsigned long long *task_base, unsigned long long *result, unsigned long long capacity,
+                         int have_out) {
+    if (threadIdx.x | blockIdx.x) return;
+    unsigned long long total = task_base[g->n_tasks];
+    result[0] = total;
+    if (have_out && total > capacity) result[1] |= 1ull;
+    if (g->bad) result[1] |= 4ull;
+}
+
+// Close the holes of the emit pass: with R = records reserved and P = R - sum(holes) valid ones, every hole slot below P
+// is filled with a valid record from [P, R).  Each block rebuilds the (tiny) plan in LDS: sort <= 1024 holes by start,
+// prefix sums of the hole parts below P and of the valid stretches above P, then a grid-stride copy.
+constexpr uint32_t kFixThreads = 1024;
+__global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_list, uint32_t n_holes, const GridParams *g, EmitTarget tg,
+                                                       unsigned long long *result) {
+    __shared__ unsigned long long hs[kFixThreads], he[kFixThreads];      // sorted holes [hs, he)
+    __shared__ unsigned long long fpre[kFixThreads + 1], tpre[kFixThreads + 2], tstart[kFixThreads + 1];
+    __shared__ unsigned long long red[kFixThreads / 64], red2[kFixThreads / 64];
+    const uint32_t i = threadIdx.x;
+    {
+        ulonglong2 h = (i < n_holes) ? hole_list[i] : make_ulonglong2(0ull, 0ull);
+        hs[i] = h.y ? h.x : ~0ull;  // empty holes sort last
+        he[i] = h.y ? h.x + h.y : ~0ull;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= kFixThreads; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t p = i ^ j;
+            if (p > i) {
+                const bool up = (i & k) == 0;
+                const unsigned long long a = hs[i], b = hs[p];
+                if ((a > b) == up) { hs[i] = b; hs[p] = a; const unsigned long long t = he[i]; he[i] = he[p]; he[p] = t; }
+            }
+            __syncthreads();
+        }
+    // totals
+    const unsigned long long R = result[2] * kUnit;
+    unsigned long long len = (hs[i] != ~0ull) ? he[i] - hs[i] : 0ull;
+    for (int off = 32; off; off >>= 1) len += __shfl_xor(len, off);
+    if ((i & 63) == 0) red[i >> 6] = len;
+    __syncthreads();
+    unsigned long long holes_total = 0;
+    for (uint32_t k = 0; k < kFixThreads / 64; k++) holes_total += red[k];
+    const unsigned long long P = R - holes_total;
+    // front part of hole i, and the valid stretch that FOLLOWS hole i-1 / precedes hole i (i = 0..n, n = real holes)
+    const bool real = hs[i] != ~0ull;
+    const unsigned long long f_len = (real && hs[i] < P) ? ((he[i] < P ? he[i] : P) - hs[i]) : 0ull;
+    const unsigned long long prev_end = (i == 0) ? 0ull : (hs[i - 1] != ~0ull ? he[i - 1] : R);
+    const unsigned long long next_start = real ? hs[i] : R;
+    const unsigned long long t_s = prev_end > P ? prev_end : P, t_e = next_start > P ? next_start : P;
+    const unsigned long long t_len = (i == 0 || hs[i - 1] != ~0ull) && t_e > t_s ? t_e - t_s : 0ull;  // one stretch past the last real hole, none after
+    tstart[i] = t_s;
+    // two 1024-wide exclusive scans (wave shuffles + one pass over the 16 wave totals)
+    unsigned long long fi = f_len, ti = t_len;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long a = __shfl_up(fi, off), b = __shfl_up(ti, off);
+        if ((i & 63) >= (uint32_t)off) { fi += a; ti += b; }
+    }
+    __syncthreads();
+    if ((i & 63) == 63) { red[i >> 6] = fi; red2[i >> 6] = ti; }
+    __syncthreads();
+    unsigned long long fo = 0, to = 0, ftot = 0, ttot = 0;
+    for (uint32_t k = 0; k < kFixThreads / 64; k++) { if (k < (i >> 6)) { fo += red[k]; to += red2[k]; } ftot += red[k]; ttot += red2[k]; }
+    fpre[i] = fo + fi - f_len; tpre[i] = to + ti - t_len;
+    if (i == 0) {
+        fpre[kFixThreads] = ftot; tpre[kFixThreads] = ttot;
+        // the stretch after the LAST slot (only when all 1024 entries are real holes)
+        const unsigned long long pe = hs[kFixThreads - 1] != ~0ull ? he[kFixThreads - 1] : R;
+        const unsigned long long ts = pe > P ? pe : P;
+        tstart[kFixThreads] = ts;
+        tpre[kFixThreads + 1] = ttot + ((hs[kFixThreads - 1] != ~0ull && R > ts) ? R - ts : 0ull);
+    }
+    __syncthreads();
+    const unsigned long long F = fpre[kFixThreads];
+    if (blockIdx.x == 0 && i == 0) {
+        result[0] = P;
+        if (P > tg.capacity) result[1] |= 1ull;
+        if (g->bad) result[1] |= 4ull;
+    }
+    if (P > tg.capacity) return;  // the caller's buffer cannot hold the table: report the size only
+    for (unsigned long long m = (unsigned long long)blockIdx.x * kFixThreads + i; m < F; m += (unsigned long long)gridDim.x * kFixThreads) {
+        uint32_t lo = 0, hi = kFixThreads;  // last k with fpre[k] <= m
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (fpre[mid] <= m) lo = mid; else hi = mid; }
+        const unsigned long long dst = hs[lo] + (m - fpre[lo]);
+        uint32_t lo2 = 0, hi2 = kFixThreads + 1;
+        while (hi2 - lo2 > 1) { const uint32_t mid = (lo2 + hi2) >> 1; if (tpre[mid] <= m) lo2 = mid; else hi2 = mid; }
+        const unsigned long long src = tstart[lo2] + (m - tpre[lo2]);
+        uint4 *d = emit_slot(tg, dst, result);
+        const uint4 *sp = emit_slot(tg, src, result);
+        if (d && sp) *d = *sp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- profiler + launch
+void Profiler::begin(const char *name, hipStream_t st) {
+    if (!enabled) return;
+    if (!created) { for (int k = 0; k < kMax; k++) { (void)hipEventCreate(&ev0[k]); (void)hipEventCreate(&ev1[k]); } created = true; }
+    if (n >= kMax) return;
+    names[n] = name;
+    (void)hipEventRecord(ev0[n], st);
+}
+void Profiler::end(hipStream_t st) {
+    if (!enabled || n >= kMax) return;
+    (void)hipEventRecord(ev1[n], st);
+    n++;
+}
+
+template <typename TOut>
+static void launch_scan(const uint32_t *in, const uint32_t *n_ptr, TOut *tmp, TOut *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_reduce<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, tmp);
+    hipLaunchKernelGGL(k_scan_tmp<TOut>, dim3(1), dim3(kScanThreads), 0, st, tmp);
+    hipLaunchKernelGGL(k_scan_apply<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, (const TOut *)tmp, out);
+}
+
+static uint32_t blocks_for(uint32_t n, uint32_t cap) {
+    uint32_t tasks = (n + 63u) / 64u;
+    uint32_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+}
+
+unsigned long long emit_scratch_records() { return (unsigned long long)kFixThreads * (kUnitsPerChunk + 1) * kUnit; }
+
+void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff) {
+    const uint32_t n = in.n;
+    const uint32_t nb = (n + 255) / 256;
+    auto P0 = [&](const char *nm) { if (prof) prof->begin(nm, st); };
+    auto P1 = [&]() { if (prof) prof->end(st); };
+    if (prof) prof->n = 0;
+    P0("grid_bounds");
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, ws.bounds, ws.result);
+    if (n) hipLaunchKernelGGL(k_bounds, dim3(nb < 256 ? nb : 256), dim3(256), 0, st, in, ws.bounds);
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, (const Bounds *)ws.bounds, ws.grid, ws.params, cutoff, ws.ncells_cap);
+    P1();
+    P0("grid_count");
+    hipLaunchKernelGGL(k_zero_cells, dim3(1024), dim3(256), 0, st, (const GridParams *)ws.grid, ws.cell_count);
+    if (n) hipLaunchKernelGGL(k_cellid, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
+    P1();
+    P0("grid_scan");
+    launch_scan<uint32_t>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, st);
+    P1();
+    P0("grid_sort");
+    if (n) {
+        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, n, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.rank_of_atom,
+                           (const uint32_t *)ws.cell_start, ws.perm, ws.slot_cell);
+    }
+    hipLaunchKernelGGL(k_gather, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.perm,
+                       (const uint32_t *)ws.slot_cell, ws.sorted);
+    P1();
+}
+
+// candidate pairs per task + their scan + total (result[0])
+void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out) {
+    EmitTarget none{nullptr, 0ull, nullptr, 0ull};
+    if (prof) prof->begin("pairs_count", st);
+    hipLaunchKernelGGL(k_pairs<kCountTasks>, dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+                       (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
+                       (const unsigned long long *)ws.task_base, none, ws.hole_list, ws.result);
+    if (prof) { prof->end(st); prof->begin("pairs_scan", st); }
+    launch_scan<unsigned long long>(ws.task_count, &ws.grid->n_tasks, ws.scan_tmp64, ws.task_base, st);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, (const GridParams *)ws.grid, (const unsigned long long *)ws.task_base, ws.result,
+                       capacity, have_out ? 1 : 0);
+    if (prof) prof->end(st);
+}
+
+// ordered fill: needs launch_count first
+void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
+    EmitTarget tg{out, capacity, nullptr, 0ull};
+    if (prof) prof->begin("pairs_fill", st);
+    hipLaunchKernelGGL(k_pairs<kFillOrdered>, dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+                       (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
+                       (const unsigned long long *)ws.task_base, tg, ws.hole_list, ws.result);
+    if (prof) prof->end(st);
+}
+
+// single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
+void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
+    EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap};
+    const uint32_t nb = blocks_for(in.n, kEmitBlocks);
+    if (prof) prof->begin("pairs_emit", st);
+    hipLaunchKernelGGL(k_pairs<kEmit>, dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
+                       (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,
+                       ws.result);
+    if (prof) { prof->end(st); prof->begin("pairs_fixup", st); }
+    hipLaunchKernelGGL(k_fixup, dim3(64), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, nb, (const GridParams *)ws.grid, tg, ws.result);
+    if (prof) prof->end(st);
+}

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-atoms", type=int, default=400_000)
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--deterministic", action="store_true", help="two-pass ordered emitter (ARP_FLAG_DETERMINISTIC)")
     return ap.parse_args()
 
 
@@ -103,7 +104,7 @@ def main():
     dsoa = to_device(soa, torch, dev)
     keep = []
     atoms = aa.atoms_from_arrays(dsoa, location=_lib.ARP_MEM_DEVICE, keep=keep)
-    prm = aa.default_params(0.1, 6.5)
+    prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic)
     stream = torch.cuda.current_stream(dev)
     ctx = aa.Context(local_rank, stream=stream.cuda_stream)
 
@@ -168,6 +169,7 @@ def main():
             "config": {
                 "workload": f"{args.workload.upper()} synthetic {n}-atom cloud per GPU (tests/synth.py gen_{args.workload}), groups='/', vdw_comp=0.1, dist_cutoff=6.5",
                 "atoms_per_gpu": n, "pairs_per_gpu": n_pairs, "sharding": "one independent structure per rank, no collective",
+                "emitter": "ordered two-pass" if args.deterministic else "single-pass",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -83,13 +83,18 @@ typedef struct arp_atoms {
     int32_t reserved;
 } arp_atoms;
 
+/* arp_params.flags.  By default pairs are emitted in one pass in an unspecified order (like the reference, whose order is
+ * that of an R*-tree walk + rayon, complex.rs:194-298).  DETERMINISTIC selects the two-pass count/scan/fill emitter
+ * whose output order is a function of the input only (about 1.3x slower). */
+#define ARP_FLAG_DETERMINISTIC 0x1u
+
 typedef struct arp_params {
     double vdw_comp;             /* mod.rs:61 vdw_comp    (default 0.1) */
     double dist_cutoff;          /* mod.rs:61 dist_cutoff (default 6.5) */
     double cov_radius[16];       /* by element class: pdbtbx covalent_single  (vdw.rs:24-28) */
     double vdw_radius[16];       /* by element class: pdbtbx van_der_waals                   */
     double h_vdw_radius;         /* Element::H van_der_waals (hbond.rs:52)                   */
-    uint32_t flags;              /* reserved, 0 */
+    uint32_t flags;              /* ARP_FLAG_* */
     uint32_t reserved;
 } arp_params;
 

@@ -42,8 +42,11 @@ def assert_pairs_equal(got, want, what=""):
 
 
 def run_both(ctx, prod, orc, groups="/", vdw_comp=0.1, cutoff=6.5):
-    got = ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff))
+    """Both emitters against the oracle: the default single-pass one is returned, the ordered one is checked here."""
     want = orc.atomic_contacts(groups, vdw_comp, cutoff)
+    ordered = ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff, deterministic=True))
+    assert_pairs_equal(ordered, want, "ordered emitter")
+    got = ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff))
     return got, want
 
 
@@ -210,9 +213,11 @@ def test_full_size_properties_1e6(ctx):
     soa = prod.soa("/")
     a = ctx.atomic_contacts(soa)
     assert len(a) > 25 * n
-    # (1) determinism: the emitted order is a function of the input only
-    b = ctx.atomic_contacts(soa)
-    assert np.array_equal(a, b)
+    # (1) the ordered emitter is deterministic byte for byte; the default single-pass emitter returns the same set
+    det = aa.default_params(deterministic=True)
+    b = ctx.atomic_contacts(soa, det)
+    assert np.array_equal(b, ctx.atomic_contacts(soa, det))
+    assert np.array_equal(canon(a), canon(b))
     # (2) permutation invariance: shuffling the atoms changes indices only
     perm = np.random.default_rng(1).permutation(n)
     inv = np.empty(n, dtype=np.uint32); inv[perm] = np.arange(n, dtype=np.uint32)
@@ -259,7 +264,14 @@ def test_enqueue_with_resident_buffers_and_capacity_error(ctx):
         c2.enqueue(atoms, prm, out.data_ptr(), len(want))
         assert c2.result() == len(want)
     got = out.cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1)
-    assert np.array_equal(got, want)
+    assert np.array_equal(canon(got), canon(want))
+    det = aa.default_params(deterministic=True)
+    c2.enqueue(atoms, det, out.data_ptr(), len(want))
+    assert c2.result() == len(want)
+    got2 = out.cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1)
+    c2.enqueue(atoms, det, out.data_ptr(), len(want))
+    assert c2.result() == len(want)
+    assert np.array_equal(got2, out.cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1)) and np.array_equal(canon(got2), canon(want))
     small = torch.zeros((1000, 4), dtype=torch.int32, device="cuda")
     guard = small.clone()
     c2.enqueue(atoms, prm, small.data_ptr(), 900)
@@ -271,7 +283,7 @@ def test_enqueue_with_resident_buffers_and_capacity_error(ctx):
     c2.profile(True)
     c2.enqueue(atoms, prm, out.data_ptr(), len(want)); c2.result()
     prof = c2.profile_read()
-    assert "pairs_fill" in prof and all(v >= 0 for v in prof.values())
+    assert "pairs_emit" in prof and all(v >= 0 for v in prof.values())
 
 
 def test_batch_of_structures(ctx):
@@ -289,7 +301,7 @@ def test_batch_of_structures(ctx):
         buf = (C.c_char * (outs[k].n * 16)).from_address(outs[k].data)
         got = np.frombuffer(buf, dtype=aa.PAIR_DTYPE).copy()
         _lib.lib.arp_pairs_free(C.byref(outs[k]))
-        assert np.array_equal(got, singles[k])
+        assert np.array_equal(canon(got), canon(singles[k]))
 
 
 # ---------------------------------------------------------------------------------------------- the table (get_contacts)
