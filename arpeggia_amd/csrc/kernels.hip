@@ -275,15 +275,25 @@ struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB)
     double r2, s_ion, s_polar, s_hphob;
 };
 
-// should_compare_entities(x, y, symmetric = true) for x in L, y in R (complex.rs:76-131, 200-206); hydrogens never
-// reach here (they are not in the grid).
-DEVFN bool candidate(const Fat &x, const Fat &y) {
-    if (!(x.attr & ARP_ATTR_LIGAND) || !(y.attr & ARP_ATTR_RECEPTOR)) return false;
-    if ((x.crm >> 16) != (y.crm >> 16)) return false;                    // :96-98 same model
-    if ((x.crm & 0xFFFFu) == (y.crm & 0xFFFFu))                          // :108 same chain
-        return (y.res_ord > 1u) && (x.res_ord < y.res_ord - 1u);         // :113
-    bool both = (x.attr & y.attr & ARP_ATTR_LIGAND) && (x.attr & y.attr & ARP_ATTR_RECEPTOR);
-    return !(both && ((x.crm & 0xFFFFu) > (y.crm & 0xFFFFu)));           // :124-129
+// should_compare_entities(x, y, symmetric = true) for x in L, y in R (complex.rs:76-131, 200-206), evaluated for both
+// orientations of an unordered pair at once: 1 = (a ligand, b receptor), 2 = (b ligand, a receptor), 0 = not a candidate.
+// At most one orientation can hold.  Hydrogens never reach here (they are not in the grid).
+DEVFN int orient(const Fat &a, const Fat &b) {
+    if ((a.crm >> 16) != (b.crm >> 16)) return 0;                        // :96-98 same model
+    const bool aL = a.attr & ARP_ATTR_LIGAND, aR = a.attr & ARP_ATTR_RECEPTOR, bL = b.attr & ARP_ATTR_LIGAND, bR = b.attr & ARP_ATTR_RECEPTOR;
+    const uint32_t ca = a.crm & 0xFFFFu, cb = b.crm & 0xFFFFu;
+    bool ab, ba;
+    if (ca == cb) {                                                      // :108 same chain, :113
+        ab = (b.res_ord > 1u) && (a.res_ord < b.res_ord - 1u);
+        ba = (a.res_ord > 1u) && (b.res_ord < a.res_ord - 1u);
+    } else {                                                             // :124-129
+        const bool both = aL && aR && bL && bR;
+        ab = !(both && ca > cb);
+        ba = !(both && cb > ca);
+    }
+    if (aL && bR && ab) return 1;
+    if (bL && aR && ba) return 2;
+    return 0;
 }
 
 DEVFN double angle_deg(const double a[3], const double b[3], const double c[3]) {
@@ -305,9 +315,7 @@ DEVFN double dihedral_deg(const double a[3], const double b[3], const double c[3
     return acos(dot / (a1 * a2)) * (180.0 / 3.14159265358979323846264338327950288);
 }
 
-// hbond.rs:36-63 / 80-107 for a fixed (donor, acceptor) assignment.  Returns 2 = (weak) hydrogen bond,
-// 1 = (weak) polar contact, 0 = nothing.  The hydrogen probe is out of line: it runs only for donor residues that
-// actually carry hydrogens.
+// hbond.rs:36-63 / 80-107: the hydrogen probe, out of line -- it runs only for donor residues that really carry hydrogens.
 __device__ __noinline__ int hydrogen_probe(const double *X, const double *Y, const double *Z, const uint32_t *res_h_idx, double lim,
                                            uint32_t p0, uint32_t p1, double dx, double dy, double dz, double ax, double ay, double az,
                                            double min_angle) {
@@ -319,11 +327,16 @@ __device__ __noinline__ int hydrogen_probe(const double *X, const double *Y, con
     }
     return 0;
 }
-DEVFN int hbond_like(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, const Fat &donor, uint32_t donor_slot,
-                     const Fat &acc, double min_angle) {
-    if ((donor.attr & kAttrResHasH) && s < prm.s_ion) {  // da_dist <= 4.0: probe every hydrogen of the donor's residue (hbond.rs:38-42)
-        const uint2 hi = hinfo[donor_slot];
-        if (hydrogen_probe(in.x, in.y, in.z, in.res_h_idx, prm.s_hacc[acc.attr & ARP_ATTR_ELEM_MASK], hi.x, hi.y, donor.x, donor.y, donor.z, acc.x, acc.y, acc.z, min_angle))
+// (weak) hydrogen bond / polar contact for the donor chosen by `donor_is_a`.  Returns 2 = hydrogen bond, 1 = polar contact, 0 = nothing.
+DEVFN int hbond_like(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, bool donor_is_a, const Fat &a, uint32_t sa,
+                     const Fat &b, uint32_t sb, double min_angle) {
+    const uint32_t dattr = donor_is_a ? a.attr : b.attr;
+    if ((dattr & kAttrResHasH) && s < prm.s_ion) {  // da_dist <= 4.0: probe every hydrogen of the donor's residue (hbond.rs:38-42)
+        const uint2 hi = hinfo[donor_is_a ? sa : sb];
+        const uint32_t acc_attr = donor_is_a ? b.attr : a.attr;
+        const double dx = donor_is_a ? a.x : b.x, dy = donor_is_a ? a.y : b.y, dz = donor_is_a ? a.z : b.z;
+        const double ax = donor_is_a ? b.x : a.x, ay = donor_is_a ? b.y : a.y, az = donor_is_a ? b.z : a.z;
+        if (hydrogen_probe(in.x, in.y, in.z, in.res_h_idx, prm.s_hacc[acc_attr & ARP_ATTR_ELEM_MASK], hi.x, hi.y, dx, dy, dz, ax, ay, az, min_angle))
             return 2;
     }
     return (s < prm.s_polar) ? 1 : 0;
@@ -343,41 +356,68 @@ __device__ __noinline__ int disulfide_probe(const double *X, const double *Y, co
     return (dih >= 60.0) && (dih <= 120.0);
 }
 
-// All rows of one candidate pair as a bit set (complex.rs:217-296).  x = ligand, y = receptor.
-DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, const Fat &x, uint32_t sx, const Fat &y,
-                        uint32_t sy, unsigned long long *result) {
-    const uint32_t ax = x.attr, ay = y.attr;
-    const uint32_t e = ((ax & ARP_ATTR_ELEM_MASK) << 4) | (ay & ARP_ATTR_ELEM_MASK);
+// All rows of one candidate pair as a bit set (complex.rs:217-296).  The rules are symmetric in the two atoms except for
+// the order in which the two donor/acceptor assignments are tried (hbond.rs:125-133: the ligand as donor first) and the
+// argument order of the disulfide dihedral; `swap` says that b is the ligand.
+DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, const Fat &a, uint32_t sa, const Fat &b,
+                        uint32_t sb, bool swap, unsigned long long *result) {
+    const uint32_t aa = a.attr, ab = b.attr;
+    const uint32_t e = ((aa & ARP_ATTR_ELEM_MASK) << 4) | (ab & ARP_ATTR_ELEM_MASK);  // the radius tables are symmetric
     uint32_t kind = 0;
     // vdw.rs:32-43
     if (s < prm.s_clash[e]) return 1u << ARP_StericClash;  // complex.rs:233-235: nothing else is looked at
     if (s < prm.s_cov[e]) {
         int ss = 0;
-        if ((ax & ay & ARP_ATTR_CYS_SG) && in.n_res) ss = disulfide_probe(in.x, in.y, in.z, in.res_id, in.res_cb, in.res_sg, x.orig, y.orig, result);
+        if ((aa & ab & ARP_ATTR_CYS_SG) && in.n_res)
+            ss = disulfide_probe(in.x, in.y, in.z, in.res_id, in.res_cb, in.res_sg, swap ? b.orig : a.orig, swap ? a.orig : b.orig, result);
         kind |= 1u << (ss ? ARP_Disulfide : ARP_CovalentBond);
     } else if (s < prm.s_vdw[e]) {
         kind |= 1u << ARP_VanDerWaalsContact;
     }
     const bool near4 = s < prm.s_ion;  // d <= 4.0
     // ionic.rs:11-22,37-57
-    const bool ionic = near4 && (((ax & ARP_ATTR_POS) && (ay & ARP_ATTR_NEG)) || ((ay & ARP_ATTR_POS) && (ax & ARP_ATTR_NEG)));
-    // hbond.rs:30-66,113-134: (e1 donor, e2 acceptor) is tried first
-    int hb = 0;
-    if ((ax & ARP_ATTR_DONOR) && (ay & ARP_ATTR_ACCEPTOR)) hb = hbond_like(in, prm, hinfo, s, x, sx, y, 90.0);
-    else if ((ay & ARP_ATTR_DONOR) && (ax & ARP_ATTR_ACCEPTOR)) hb = hbond_like(in, prm, hinfo, s, y, sy, x, 90.0);
-    // complex.rs:240-251
-    if (ionic) kind |= 1u << (hb == 2 ? ARP_SaltBridge : ARP_IonicBond);
-    else if (hb) kind |= 1u << (hb == 2 ? ARP_HydrogenBond : ARP_PolarContact);
+    const bool ionic = near4 && (((aa & ARP_ATTR_POS) && (ab & ARP_ATTR_NEG)) || ((ab & ARP_ATTR_POS) && (aa & ARP_ATTR_NEG)));
+    const bool a_acc = aa & ARP_ATTR_ACCEPTOR, b_acc = ab & ARP_ATTR_ACCEPTOR;
+    // hbond.rs:30-66,113-134
+    {
+        const bool a2b = (aa & ARP_ATTR_DONOR) && b_acc, b2a = (ab & ARP_ATTR_DONOR) && a_acc;
+        int hb = 0;
+        if (a2b | b2a) hb = hbond_like(in, prm, hinfo, s, swap ? !b2a : a2b, a, sa, b, sb, 90.0);
+        // complex.rs:240-251
+        if (ionic) kind |= 1u << (hb == 2 ? ARP_SaltBridge : ARP_IonicBond);
+        else if (hb) kind |= 1u << (hb == 2 ? ARP_HydrogenBond : ARP_PolarContact);
+    }
     // hbond.rs:74-110,181-201
-    int wk = 0;
-    if ((ax & ARP_ATTR_WEAK_DONOR) && (ay & ARP_ATTR_ACCEPTOR)) wk = hbond_like(in, prm, hinfo, s, x, sx, y, 130.0);
-    else if ((ay & ARP_ATTR_WEAK_DONOR) && (ax & ARP_ATTR_ACCEPTOR)) wk = hbond_like(in, prm, hinfo, s, y, sy, x, 130.0);
-    if (wk) kind |= 1u << (wk == 2 ? ARP_WeakHydrogenBond : ARP_WeakPolarContact);
+    {
+        const bool a2b = (aa & ARP_ATTR_WEAK_DONOR) && b_acc, b2a = (ab & ARP_ATTR_WEAK_DONOR) && a_acc;
+        if (a2b | b2a) {
+            const int wk = hbond_like(in, prm, hinfo, s, swap ? !b2a : a2b, a, sa, b, sb, 130.0);
+            if (wk) kind |= 1u << (wk == 2 ? ARP_WeakHydrogenBond : ARP_WeakPolarContact);
+        }
+    }
     // ionic.rs:25-35,59-81
-    if (near4 && ((ax & ay & ARP_ATTR_POS) || (ax & ay & ARP_ATTR_NEG))) kind |= 1u << ARP_IonicRepulsion;
+    if (near4 && ((aa & ab & ARP_ATTR_POS) || (aa & ab & ARP_ATTR_NEG))) kind |= 1u << ARP_IonicRepulsion;
     // hydrophobic.rs:10-24
-    if ((ax & ay & ARP_ATTR_HYDROPHOBIC) && s < prm.s_hphob) kind |= 1u << ARP_HydrophobicContact;
+    if ((aa & ab & ARP_ATTR_HYDROPHOBIC) && s < prm.s_hphob) kind |= 1u << ARP_HydrophobicContact;
     return kind;
+}
+
+// (float) of the correctly rounded f64 square root -- what the reference stores in the table (mod.rs:148) -- without the
+// library sqrt: f32 rsq seed, two coupled Newton steps and a residual correction in f64 leave < 2 ulp(f64) of error, which
+// cannot change the f32 rounding unless the result sits within a few f64 ulps of an f32 rounding boundary; only then
+// (probability ~1e-8) the exact library routine runs.
+DEVFN float dist_f32(double s) {
+    if (!(s > 1e-30 && s < 1e30)) return (float)sqrt(s);
+    const double r = (double)__frsqrt_rn((float)s);
+    double y = s * r, h = 0.5 * r;
+    double e = __fma_rn(-h, y, 0.5);
+    y = __fma_rn(y, e, y); h = __fma_rn(h, e, h);
+    e = __fma_rn(-h, y, 0.5);
+    y = __fma_rn(y, e, y); h = __fma_rn(h, e, h);
+    y = __fma_rn(__fma_rn(-y, y, s), h, y);
+    const uint32_t low = (uint32_t)__double_as_longlong(y) & 0x1FFFFFFFu;  // the 29 bits a cast to f32 drops
+    if (low - (0x10000000u - 16u) <= 32u) return (float)sqrt(s);             // near the midpoint: decide exactly
+    return (float)y;
 }
 
 // ---------------------------------------------------------------------------------------------- pair search + launch

@@ -111,8 +111,8 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
         a = so.fat[ent.x]; b = so.fat[ent.y];
         s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
         if (s <= prm.r2) {  // rstar: inclusive
-            if (candidate(a, b)) valid = true;
-            else if (candidate(b, a)) { valid = true; swap = true; }
+            const int o = orient(a, b);
+            valid = o != 0; swap = o == 2;
         }
     }
     const unsigned long long vm = __ballot(valid);
@@ -120,9 +120,9 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
     if (MODE != kCountTasks) {
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (valid) {
-            r.w = swap ? classify(in, prm, so.hinfo, s, b, ent.y, a, ent.x, result) : classify(in, prm, so.hinfo, s, a, ent.x, b, ent.y, result);
+            r.w = classify(in, prm, so.hinfo, s, a, ent.x, b, ent.y, swap, result);
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
-            r.z = __float_as_uint((float)sqrt(s));
+            r.z = __float_as_uint(dist_f32(s));
         }
         if (MODE == kFillOrdered) {
             const unsigned long long pos = base + emitted + mbcnt(vm);

@@ -37,8 +37,10 @@ def assert_pairs_equal(got, want, what=""):
     bad = np.flatnonzero(g["kind"] != w["kind"])
     assert len(bad) == 0, f"{what}: {len(bad)} kind mismatches, first: i={g['i'][bad[0]]} j={g['j'][bad[0]]} got={g['kind'][bad[0]]:#x} want={w['kind'][bad[0]]:#x} d={w['dist'][bad[0]]}"
     assert np.abs(g["dist"].astype(np.float64) - w["dist"]).max(initial=0.0) <= DIST_TOL, f"{what}: distance tolerance"
-    # the table stores (f32) distance (mod.rs:148); report bit-exactness of that narrowing
-    return float((g["dist"] == w["dist"].astype(np.float32)).mean()) if len(g) else 1.0
+    # the table stores (f32) distance (mod.rs:148): the narrowing of the correctly rounded f64 distance is reproduced bit for bit
+    exact = float((g["dist"] == w["dist"].astype(np.float32)).mean()) if len(g) else 1.0
+    assert exact == 1.0, f"{what}: f32 distances not bit-identical ({exact})"
+    return exact
 
 
 def run_both(ctx, prod, orc, groups="/", vdw_comp=0.1, cutoff=6.5):
