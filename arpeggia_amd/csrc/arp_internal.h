@@ -82,10 +82,13 @@ struct Workspace {
     unsigned long long *task_base;  // n/64 + 2
     uint32_t *scan_tmp;       // block sums (1024 + 1)
     unsigned long long *scan_tmp64;
-    unsigned long long *result;  // [0] = total pairs, [1] = flags, [2] = emit allocator head (64-record units)
+    unsigned long long *result;  // [0] = total pairs, [1] = flags, [2] = emit allocator head (64-record units), [3] = deferred candidates
     ulonglong2 *hole_list;    // emit mode: one (start, length) per block
     arp_pair *scratch;        // emit mode: home of positions >= the caller's capacity until k_fixup has closed the holes
     unsigned long long scratch_cap;
+    uint32_t *task_ctr;       // [3 modes][8 block groups]: next wave-task of the group
+    uint2 *defer_list;        // emit mode: candidates whose classification needs a hydrogen / disulfide probe
+    unsigned long long defer_cap;
     uint32_t ncells_cap;
     uint32_t n_cap;
 };

@@ -137,7 +137,8 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.hinfo, cap);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);
-    A(w.hole_list, 1024); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
+    A(w.hole_list, 1024); A(w.task_ctr, 32); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
+    w.defer_cap = std::max<uint64_t>(8 * cap, 1u << 20); A(w.defer_list, w.defer_cap);
 #undef A
     w.n_cap = (uint32_t)cap;
     w.ncells_cap = (uint32_t)ccap;
@@ -278,6 +279,7 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
 
 static arp_status flags_to_status(unsigned long long flags) {
     if (flags & 4ull) { set_error("non-finite atom coordinate"); return ARP_ERR_BAD_INPUT; }
+    if (flags & 8ull) { set_error("deferred-probe list overflow; rerun with ARP_FLAG_DETERMINISTIC"); return ARP_ERR_CAPACITY; }
     if (flags & 2ull) { set_error("CYS SG..SG covalent pair whose residue has no CB (the reference panics in is_disulfide, vdw.rs:58)"); return ARP_ERR_BAD_INPUT; }
     return ARP_OK;
 }

@@ -45,9 +45,10 @@ DEVFN void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefron
 constexpr uint32_t kAttrResHasH = 0x80000000u;  // internal: the atom's residue carries hydrogens (set by k_gather)
 
 // ---------------------------------------------------------------------------------------------- grid build
-__global__ void k_init(Bounds *b, unsigned long long *result) {
+__global__ void k_init(Bounds *b, unsigned long long *result, uint32_t *task_ctr) {
+    if (threadIdx.x < 24) task_ctr[threadIdx.x] = 0;
     if (threadIdx.x < 3) { b->mn[threadIdx.x] = ~0ull; b->mx[threadIdx.x] = 0ull; }
-    if (threadIdx.x == 0) { b->n_models = 0; b->bad = 0; result[0] = 0; result[1] = 0; result[2] = 0; }
+    if (threadIdx.x == 0) { b->n_models = 0; b->bad = 0; result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; }
 }
 
 // Bounding box of the heavy atoms: registers -> wave shuffles -> LDS -> one atomic set per block (<= 256 blocks).
@@ -277,23 +278,20 @@ struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB)
 
 // should_compare_entities(x, y, symmetric = true) for x in L, y in R (complex.rs:76-131, 200-206), evaluated for both
 // orientations of an unordered pair at once: 1 = (a ligand, b receptor), 2 = (b ligand, a receptor), 0 = not a candidate.
-// At most one orientation can hold.  Hydrogens never reach here (they are not in the grid).
+// At most one orientation can hold.  Hydrogens never reach here (they are not in the grid).  Written without branches:
+// the exact phase is instruction-issue bound and every divergent branch costs a handful of scalar exec-mask instructions.
 DEVFN int orient(const Fat &a, const Fat &b) {
-    if ((a.crm >> 16) != (b.crm >> 16)) return 0;                        // :96-98 same model
-    const bool aL = a.attr & ARP_ATTR_LIGAND, aR = a.attr & ARP_ATTR_RECEPTOR, bL = b.attr & ARP_ATTR_LIGAND, bR = b.attr & ARP_ATTR_RECEPTOR;
+    const bool same_model = (a.crm >> 16) == (b.crm >> 16);             // :96-98
     const uint32_t ca = a.crm & 0xFFFFu, cb = b.crm & 0xFFFFu;
-    bool ab, ba;
-    if (ca == cb) {                                                      // :108 same chain, :113
-        ab = (b.res_ord > 1u) && (a.res_ord < b.res_ord - 1u);
-        ba = (a.res_ord > 1u) && (b.res_ord < a.res_ord - 1u);
-    } else {                                                             // :124-129
-        const bool both = aL && aR && bL && bR;
-        ab = !(both && ca > cb);
-        ba = !(both && cb > ca);
-    }
-    if (aL && bR && ab) return 1;
-    if (bL && aR && ba) return 2;
-    return 0;
+    const bool aL = a.attr & ARP_ATTR_LIGAND, aR = a.attr & ARP_ATTR_RECEPTOR, bL = b.attr & ARP_ATTR_LIGAND, bR = b.attr & ARP_ATTR_RECEPTOR;
+    // same chain (:108,:113): (e2 > 1) && (e1 < e2 - 1)  <=>  e1 + 1 < e2   (ordinals are far below 2^32 - 1)
+    const bool ab_chain = a.res_ord + 1u < b.res_ord, ba_chain = b.res_ord + 1u < a.res_ord;
+    const bool both = aL & aR & bL & bR;                                 // :124-129
+    const bool ab_cross = !(both & (ca > cb)), ba_cross = !(both & (cb > ca));
+    const bool same_chain = ca == cb;
+    const bool ab = same_chain ? ab_chain : ab_cross, ba = same_chain ? ba_chain : ba_cross;
+    const bool o1 = same_model & aL & bR & ab, o2 = same_model & bL & aR & ba;
+    return o1 ? 1 : (o2 ? 2 : 0);
 }
 
 DEVFN double angle_deg(const double a[3], const double b[3], const double c[3]) {
@@ -328,20 +326,6 @@ __device__ __noinline__ int hydrogen_probe(const double *X, const double *Y, con
     return 0;
 }
 // (weak) hydrogen bond / polar contact for the donor chosen by `donor_is_a`.  Returns 2 = hydrogen bond, 1 = polar contact, 0 = nothing.
-DEVFN int hbond_like(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, bool donor_is_a, const Fat &a, uint32_t sa,
-                     const Fat &b, uint32_t sb, double min_angle) {
-    const uint32_t dattr = donor_is_a ? a.attr : b.attr;
-    if ((dattr & kAttrResHasH) && s < prm.s_ion) {  // da_dist <= 4.0: probe every hydrogen of the donor's residue (hbond.rs:38-42)
-        const uint2 hi = hinfo[donor_is_a ? sa : sb];
-        const uint32_t acc_attr = donor_is_a ? b.attr : a.attr;
-        const double dx = donor_is_a ? a.x : b.x, dy = donor_is_a ? a.y : b.y, dz = donor_is_a ? a.z : b.z;
-        const double ax = donor_is_a ? b.x : a.x, ay = donor_is_a ? b.y : a.y, az = donor_is_a ? b.z : a.z;
-        if (hydrogen_probe(in.x, in.y, in.z, in.res_h_idx, prm.s_hacc[acc_attr & ARP_ATTR_ELEM_MASK], hi.x, hi.y, dx, dy, dz, ax, ay, az, min_angle))
-            return 2;
-    }
-    return (s < prm.s_polar) ? 1 : 0;
-}
-
 // vdw.rs:46-80, out of line (rare): 1 = disulfide, 0 = plain covalent, sets the error flag where the reference panics
 __device__ __noinline__ int disulfide_probe(const double *X, const double *Y, const double *Z, const uint32_t *res_id, const uint32_t *res_cb,
                                             const uint32_t *res_sg, uint32_t ix, uint32_t iy, unsigned long long *result) {
@@ -356,50 +340,58 @@ __device__ __noinline__ int disulfide_probe(const double *X, const double *Y, co
     return (dih >= 60.0) && (dih <= 120.0);
 }
 
+constexpr uint32_t kDeferKind = 0xFFFFFFFFu;  // classify<false>: the pair needs a hydrogen / disulfide probe, decide it in the deferred pass
+
+// (weak) hydrogen bond test of hbond.rs:36-58 / 80-102 for the donor chosen by `donor_is_a`: true iff some hydrogen of the donor's
+// residue satisfies the distance and angle conditions.  Only called for donors whose residue carries hydrogens.
+DEVFN bool hbond_probe(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, bool donor_is_a, const Fat &a, uint32_t sa, const Fat &b,
+                       uint32_t sb, double min_angle) {
+    const uint2 hi = hinfo[donor_is_a ? sa : sb];
+    const uint32_t acc_attr = donor_is_a ? b.attr : a.attr;
+    const double dx = donor_is_a ? a.x : b.x, dy = donor_is_a ? a.y : b.y, dz = donor_is_a ? a.z : b.z;
+    const double ax = donor_is_a ? b.x : a.x, ay = donor_is_a ? b.y : a.y, az = donor_is_a ? b.z : a.z;
+    return hydrogen_probe(in.x, in.y, in.z, in.res_h_idx, prm.s_hacc[acc_attr & ARP_ATTR_ELEM_MASK], hi.x, hi.y, dx, dy, dz, ax, ay, az, min_angle) != 0;
+}
+
 // All rows of one candidate pair as a bit set (complex.rs:217-296).  The rules are symmetric in the two atoms except for
 // the order in which the two donor/acceptor assignments are tried (hbond.rs:125-133: the ligand as donor first) and the
-// argument order of the disulfide dihedral; `swap` says that b is the ligand.
+// argument order of the disulfide dihedral; `swap` says that b is the ligand.  Everything on the common path is
+// straight-line predicate arithmetic; only the rare probes branch (PROBES) or defer the pair (!PROBES).
+template <bool PROBES>
 DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, const Fat &a, uint32_t sa, const Fat &b,
                         uint32_t sb, bool swap, unsigned long long *result) {
-    const uint32_t aa = a.attr, ab = b.attr;
+    const uint32_t aa = a.attr, ab = b.attr, both = aa & ab;
     const uint32_t e = ((aa & ARP_ATTR_ELEM_MASK) << 4) | (ab & ARP_ATTR_ELEM_MASK);  // the radius tables are symmetric
-    uint32_t kind = 0;
-    // vdw.rs:32-43
-    if (s < prm.s_clash[e]) return 1u << ARP_StericClash;  // complex.rs:233-235: nothing else is looked at
-    if (s < prm.s_cov[e]) {
-        int ss = 0;
-        if ((aa & ab & ARP_ATTR_CYS_SG) && in.n_res)
-            ss = disulfide_probe(in.x, in.y, in.z, in.res_id, in.res_cb, in.res_sg, swap ? b.orig : a.orig, swap ? a.orig : b.orig, result);
-        kind |= 1u << (ss ? ARP_Disulfide : ARP_CovalentBond);
-    } else if (s < prm.s_vdw[e]) {
-        kind |= 1u << ARP_VanDerWaalsContact;
+    const double t_clash = prm.s_clash[e], t_cov = prm.s_cov[e], t_vdw = prm.s_vdw[e];
+    const bool clash = s < t_clash, cov = s < t_cov, vdw = s < t_vdw;                 // vdw.rs:32-43 (strict <)
+    const bool near4 = s < prm.s_ion, near35 = s < prm.s_polar, near45 = s < prm.s_hphob;  // d <= 4.0 / 3.5 / 4.5
+    // attribute bit positions: DONOR 4, ACCEPTOR 5, WEAK_DONOR 6, POS 7, NEG 8, HYDROPHOBIC 9, CYS_SG 10, has-H 31
+    const bool d_ab = (aa >> 4) & (ab >> 5) & 1u, d_ba = (ab >> 4) & (aa >> 5) & 1u;  // hbond.rs:113-134
+    const bool w_ab = (aa >> 6) & (ab >> 5) & 1u, w_ba = (ab >> 6) & (aa >> 5) & 1u;  // hbond.rs:181-201
+    const bool strong = d_ab | d_ba, weak = w_ab | w_ba;
+    const bool sd_a = swap ? !d_ba : d_ab, wd_a = swap ? !w_ba : w_ab;                // the ligand is tried as donor first
+    const bool s_hasH = (sd_a ? aa : ab) >> 31, w_hasH = (wd_a ? aa : ab) >> 31;
+    const bool need_hs = strong & near4 & s_hasH, need_hw = weak & near4 & w_hasH;    // hbond.rs:37,81: da_dist <= 4.0
+    const bool need_ss = cov & !clash & ((both >> 10) & 1u) & (in.n_res != 0u);       // vdw.rs:46-53
+    bool hb2 = false, wk2 = false, ss = false;
+    if (!clash && (need_hs | need_hw | need_ss)) {                                     // rare
+        if (!PROBES) return kDeferKind;
+        if (need_ss) ss = disulfide_probe(in.x, in.y, in.z, in.res_id, in.res_cb, in.res_sg, swap ? b.orig : a.orig, swap ? a.orig : b.orig, result);
+        if (need_hs) hb2 = hbond_probe(in, prm, hinfo, sd_a, a, sa, b, sb, 90.0);
+        if (need_hw) wk2 = hbond_probe(in, prm, hinfo, wd_a, a, sa, b, sb, 130.0);
     }
-    const bool near4 = s < prm.s_ion;  // d <= 4.0
-    // ionic.rs:11-22,37-57
-    const bool ionic = near4 && (((aa & ARP_ATTR_POS) && (ab & ARP_ATTR_NEG)) || ((ab & ARP_ATTR_POS) && (aa & ARP_ATTR_NEG)));
-    const bool a_acc = aa & ARP_ATTR_ACCEPTOR, b_acc = ab & ARP_ATTR_ACCEPTOR;
-    // hbond.rs:30-66,113-134
-    {
-        const bool a2b = (aa & ARP_ATTR_DONOR) && b_acc, b2a = (ab & ARP_ATTR_DONOR) && a_acc;
-        int hb = 0;
-        if (a2b | b2a) hb = hbond_like(in, prm, hinfo, s, swap ? !b2a : a2b, a, sa, b, sb, 90.0);
-        // complex.rs:240-251
-        if (ionic) kind |= 1u << (hb == 2 ? ARP_SaltBridge : ARP_IonicBond);
-        else if (hb) kind |= 1u << (hb == 2 ? ARP_HydrogenBond : ARP_PolarContact);
-    }
-    // hbond.rs:74-110,181-201
-    {
-        const bool a2b = (aa & ARP_ATTR_WEAK_DONOR) && b_acc, b2a = (ab & ARP_ATTR_WEAK_DONOR) && a_acc;
-        if (a2b | b2a) {
-            const int wk = hbond_like(in, prm, hinfo, s, swap ? !b2a : a2b, a, sa, b, sb, 130.0);
-            if (wk) kind |= 1u << (wk == 2 ? ARP_WeakHydrogenBond : ARP_WeakPolarContact);
-        }
-    }
-    // ionic.rs:25-35,59-81
-    if (near4 && ((aa & ab & ARP_ATTR_POS) || (aa & ab & ARP_ATTR_NEG))) kind |= 1u << ARP_IonicRepulsion;
-    // hydrophobic.rs:10-24
-    if ((aa & ab & ARP_ATTR_HYDROPHOBIC) && s < prm.s_hphob) kind |= 1u << ARP_HydrophobicContact;
-    return kind;
+    const bool ionic = near4 & ((((aa >> 7) & (ab >> 8)) | ((ab >> 7) & (aa >> 8))) & 1u);     // ionic.rs:11-22,37-57
+    const bool repel = near4 & (((both >> 7) | (both >> 8)) & 1u);                              // ionic.rs:25-35,59-81
+    const bool hphob = near45 & ((both >> 9) & 1u);                                            // hydrophobic.rs:10-24
+    const bool hb1 = strong & near35, wk1 = weak & near35;                                      // polar contacts (hbond.rs:60-63)
+    uint32_t kind = cov ? (1u << (ss ? ARP_Disulfide : ARP_CovalentBond)) : (vdw ? (1u << ARP_VanDerWaalsContact) : 0u);
+    // complex.rs:240-251
+    const uint32_t electro = ionic ? (hb2 ? ARP_SaltBridge : ARP_IonicBond) : (hb2 ? ARP_HydrogenBond : ARP_PolarContact);
+    kind |= (ionic | hb2 | hb1) ? (1u << electro) : 0u;
+    kind |= wk2 ? (1u << ARP_WeakHydrogenBond) : (wk1 ? (1u << ARP_WeakPolarContact) : 0u);
+    kind |= repel ? (1u << ARP_IonicRepulsion) : 0u;
+    kind |= hphob ? (1u << ARP_HydrophobicContact) : 0u;
+    return clash ? (1u << ARP_StericClash) : kind;                                              // complex.rs:233-235
 }
 
 // (float) of the correctly rounded f64 square root -- what the reference stores in the table (mod.rs:148) -- without the

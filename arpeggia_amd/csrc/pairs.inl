@@ -26,7 +26,8 @@ constexpr int kQueue = 128;
 constexpr uint32_t kChunk = 256;            // neighbour records per staged chunk (4 KB)
 constexpr uint32_t kBlock = 16;             // prefilter tests per lane between two compaction steps
 constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
-constexpr uint32_t kEmitBlocks = 256 * 3;   // emit mode: bounds the number of holes (<= 1024, one k_fixup thread each)
+constexpr uint32_t kEmitBlocks = 896;       // emit mode: 3.5 blocks per CU; with the 128 deferred blocks <= 1024 holes (one k_fixup thread each)
+constexpr uint32_t kGrab = 2;              // wave-tasks drawn per atomic
 constexpr uint32_t kUnit = 64;              // records per flush = one wave-wide 16-byte store
 constexpr uint32_t kUnitsPerChunk = 32;     // 2048 records per global allocation
 
@@ -46,16 +47,10 @@ DEVFN void push_pass(uint32_t &mask, float d2, float r2f) {
     asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2f) : "vcc");
 }
 
-// Blocks b and b+8 share an XCD (and its private L2): give every XCD one contiguous eighth of the task range so that
-// the neighbour windows its waves stage are served from that L2 instead of being re-fetched by all eight.
-DEVFN uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nb) {
-    const uint32_t xcd = bid & 7u, idx = bid >> 3, q = nb >> 3, r = nb & 7u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
-}
-
 struct EmitTarget {  // positions >= capacity spill into the engine's scratch so that a buffer of exactly P records suffices
     arp_pair *out; unsigned long long capacity;
     arp_pair *scratch; unsigned long long scratch_cap;
+    uint2 *defer_list; unsigned long long defer_cap;  // candidates whose classification needs a hydrogen / disulfide probe
 };
 DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned long long *result) {
     if (pos < tg.capacity) return reinterpret_cast<uint4 *>(tg.out) + pos;
@@ -99,8 +94,10 @@ DEVFN void flush_unit(WaveLds<MODE> &w, BlockLds &bl, uint32_t &rqlen, const Emi
     if (d) *d = r;
 }
 
-// Phase 2 on up to 64 survivors.  Returns the number of valid candidate pairs of the batch.
-template <int MODE>
+// Phase 2 on up to 64 survivors.  Returns the number of valid candidate pairs of the batch.  PROBES == false keeps the
+// rare data-dependent rules (hydrogen-bond angle test over the donor residue's hydrogens, disulfide dihedral) out of the
+// hot kernel -- they cost it half its occupancy in registers: such pairs go to a list that k_pairs_deferred finishes.
+template <int MODE, bool PROBES>
 DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
                              unsigned long long base, uint32_t emitted, uint32_t &rqlen, const EmitTarget &tg, unsigned long long *result,
                              uint32_t lane) {
@@ -110,17 +107,16 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
     if (active) {
         a = so.fat[ent.x]; b = so.fat[ent.y];
         s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
-        if (s <= prm.r2) {  // rstar: inclusive
-            const int o = orient(a, b);
-            valid = o != 0; swap = o == 2;
-        }
+        const int o = orient(a, b);
+        valid = (s <= prm.r2) & (o != 0);  // rstar: inclusive
+        swap = o == 2;
     }
-    const unsigned long long vm = __ballot(valid);
+    unsigned long long vm = __ballot(valid);
     const uint32_t nvalid = (uint32_t)__popcll(vm);
     if (MODE != kCountTasks) {
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (valid) {
-            r.w = classify(in, prm, so.hinfo, s, a, ent.x, b, ent.y, swap, result);
+            r.w = classify<PROBES>(in, prm, so.hinfo, s, a, ent.x, b, ent.y, swap, result);
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
             r.z = __float_as_uint(dist_f32(s));
         }
@@ -128,18 +124,72 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
             const unsigned long long pos = base + emitted + mbcnt(vm);
             if (valid && pos < tg.capacity) reinterpret_cast<uint4 *>(tg.out)[pos] = r;
         } else {
+            if (!PROBES) {
+                const bool defer = valid && r.w == kDeferKind;
+                const unsigned long long dm = __ballot(defer);
+                if (dm) {  // rare: hand the candidate to the deferred pass (one aggregated atomic per wave)
+                    unsigned long long dbase = 0;
+                    if (lane == 0) dbase = atomicAdd(&result[3], (unsigned long long)__popcll(dm));
+                    dbase = __shfl(dbase, 0);
+                    if (defer) {
+                        const unsigned long long p = dbase + mbcnt(dm);
+                        if (p < tg.defer_cap) tg.defer_list[p] = ent; else atomicOr(&result[1], 8ull);
+                    }
+                    valid = valid && !defer;
+                    vm = __ballot(valid);
+                }
+            }
             if (valid) w.rq[rqlen + mbcnt(vm)] = r;
-            rqlen += nvalid;
+            rqlen += (uint32_t)__popcll(vm);
             if (rqlen >= kUnit) flush_unit<MODE>(w, bl, rqlen, tg, result, lane);
         }
     }
     return nvalid;
 }
 
-template <int MODE>
+// Block epilogue of the emit mode: merge the < 64 leftover records of the four waves so that the block leaves exactly ONE
+// hole (the unused tail of its last chunk) behind.  Every wave of the block must call it.
+template <typename WL>
+DEVFN void emit_epilogue(WL *wl, BlockLds &bl, uint32_t rqlen, const EmitTarget &tg, ulonglong2 *hole, unsigned long long *result,
+                         uint32_t wave, uint32_t lane) {
+    if (lane == 0) bl.left[wave] = rqlen;
+    __syncthreads();
+    uint32_t offs[kWavesPerBlock + 1];
+    offs[0] = 0;
+    for (int v = 0; v < kWavesPerBlock; v++) offs[v + 1] = offs[v] + bl.left[v];
+    const uint32_t total = offs[kWavesPerBlock], units = (total + kUnit - 1) / kUnit;
+    auto write_unit = [&](uint32_t uidx) -> uint32_t {
+        const uint32_t unit = alloc_unit(bl, &result[2], lane);
+        const uint32_t g = uidx * kUnit + lane;
+        if (g < total) {
+            const uint32_t sw = (g >= offs[1]) + (g >= offs[2]) + (g >= offs[3]);
+            uint4 *d = emit_slot(tg, (unsigned long long)unit * kUnit + lane, result);
+            if (d) *d = wl[sw].rq[g - offs[sw]];
+        }
+        return unit;
+    };
+    if (units > 1 && wave < units - 1) write_unit(wave);  // full units first ...
+    __syncthreads();
+    if (wave == 0) {                                        // ... the partial one last, so the hole behind it is contiguous
+        unsigned long long hs = 0, hl = 0;
+        if (units >= 1) {
+            const uint32_t unit = write_unit(units - 1);
+            const unsigned long long st = bl.alloc_state;
+            hs = (unsigned long long)unit * kUnit + (total - (units - 1) * kUnit);
+            hl = ((st >> 32) + kUnitsPerChunk) * kUnit - hs;
+        } else {
+            const unsigned long long st = bl.alloc_state;
+            const uint32_t first = (uint32_t)(st >> 32), used = (uint32_t)st;
+            if (first != 0xFFFFFFFFu) { hs = ((unsigned long long)first + used) * kUnit; hl = (unsigned long long)(kUnitsPerChunk - used) * kUnit; }
+        }
+        if (lane == 0) *hole = make_ulonglong2(hs, hl);
+    }
+}
+
+template <int MODE, bool PROBES>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
                                                                Sorted so, uint32_t *task_count, const unsigned long long *task_base,
-                                                               EmitTarget tg, ulonglong2 *hole_list, unsigned long long *result) {
+                                                               EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     __shared__ LdsParams prm;
     __shared__ WaveLds<MODE> wl[kWavesPerBlock];
     __shared__ BlockLds bl;
@@ -157,12 +207,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
     const float r2f = dprm->r2f;
     WaveLds<MODE> &w = wl[wave];
-    const uint32_t per_block = (n_tasks + gridDim.x - 1) / gridDim.x;
-    const uint32_t t_begin = min(n_tasks, xcd_contiguous_block(blockIdx.x, gridDim.x) * per_block), t_end = min(n_tasks, t_begin + per_block);
+    // Task distribution: blocks b and b+8 share an XCD (and its private L2), so block group (b mod 8) owns one contiguous
+    // eighth of the task range -- the windows its waves stage come out of that L2 -- and inside a group the waves draw
+    // kGrab tasks at a time from the group's counter, which evens out the very different costs of surface and core tasks.
+    const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
+    const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
+    uint32_t *ctr = task_ctr + MODE * 8 + group;
     uint32_t rqlen = 0;  // emit mode: records waiting in w.rq (wave-uniform)
     uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); emit mode carries them across tasks
 #pragma unroll 1
-    for (uint32_t t = t_begin + wave; t < t_end; t += kWavesPerBlock) {
+    for (;;) {
+    uint32_t t0 = 0;
+    if (lane == 0) t0 = atomicAdd(ctr, kGrab);
+    t0 = g_lo + __builtin_amdgcn_readfirstlane(t0);
+    if (t0 >= g_hi) break;
+    const uint32_t t1 = min(t0 + kGrab, g_hi);
+#pragma unroll 1
+    for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t a = t * 64u + lane;  // this lane's home slot
         const bool have = a < n_heavy;
         float4 home = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -238,7 +299,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
                             wave_lds_fence();  // lanes read entries other lanes wrote
                             const uint2 ent = w.queue[qlen + lane];
                             wave_lds_fence();
-                            emitted += process_batch<MODE>(in, prm, so, w, bl, ent, true, base, emitted, rqlen, tg, result, lane);
+                            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, true, base, emitted, rqlen, tg, result, lane);
                         }
                     }
                 }
@@ -250,10 +311,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
             wave_lds_fence();
             const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
             wave_lds_fence();
-            emitted += process_batch<MODE>(in, prm, so, w, bl, ent, act, base, emitted, rqlen, tg, result, lane);
+            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, base, emitted, rqlen, tg, result, lane);
             qlen = 0;
         }
         if (MODE == kCountTasks && lane == 0) task_count[t] = emitted;
+    }
     }
     if (MODE == kEmit) {
         if (qlen) {
@@ -261,43 +323,39 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
             wave_lds_fence();
             const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
             wave_lds_fence();
-            process_batch<MODE>(in, prm, so, w, bl, ent, act, 0ull, 0u, rqlen, tg, result, lane);
+            process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, 0ull, 0u, rqlen, tg, result, lane);
         }
-        // Block epilogue: merge the < 64 leftover records of the four waves so that the block leaves exactly ONE hole
-        // (the unused tail of its last chunk) behind.
-        if (lane == 0) bl.left[wave] = rqlen;
-        __syncthreads();
-        uint32_t offs[kWavesPerBlock + 1];
-        offs[0] = 0;
-        for (int v = 0; v < kWavesPerBlock; v++) offs[v + 1] = offs[v] + bl.left[v];
-        const uint32_t total = offs[kWavesPerBlock], units = (total + kUnit - 1) / kUnit;
-        auto write_unit = [&](uint32_t uidx) -> uint32_t {
-            const uint32_t unit = alloc_unit(bl, &result[2], lane);
-            const uint32_t g = uidx * kUnit + lane;
-            if (g < total) {
-                const uint32_t sw = (g >= offs[1]) + (g >= offs[2]) + (g >= offs[3]);
-                uint4 *d = emit_slot(tg, (unsigned long long)unit * kUnit + lane, result);
-                if (d) *d = wl[sw].rq[g - offs[sw]];
-            }
-            return unit;
-        };
-        if (units > 1 && wave < units - 1) write_unit(wave);  // full units first ...
-        __syncthreads();
-        if (wave == 0) {                                        // ... the partial one last, so the hole behind it is contiguous
-            unsigned long long hs = 0, hl = 0;
-            if (units >= 1) {
-                const uint32_t unit = write_unit(units - 1);
-                const unsigned long long st = bl.alloc_state;
-                hs = (unsigned long long)unit * kUnit + (total - (units - 1) * kUnit);
-                hl = ((st >> 32) + kUnitsPerChunk) * kUnit - hs;
-            } else {
-                const unsigned long long st = bl.alloc_state;
-                const uint32_t first = (uint32_t)(st >> 32), used = (uint32_t)st;
-                if (first != 0xFFFFFFFFu) { hs = ((unsigned long long)first + used) * kUnit; hl = (unsigned long long)(kUnitsPerChunk - used) * kUnit; }
-            }
-            if (lane == 0) hole_list[blockIdx.x] = make_ulonglong2(hs, hl);
-        }
+        emit_epilogue(wl, bl, rqlen, tg, hole_list + blockIdx.x, result, wave, lane);
     }
+}
+
+// The deferred pass of the emit mode: candidates that need a hydrogen or disulfide probe, classified with the probes
+// inline and emitted through the same allocator (its blocks add their own holes to the list k_fixup closes).
+constexpr uint32_t kDeferBlocks = 128;
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms in, const DevParams *dprm, Sorted so, EmitTarget tg,
+                                                                         ulonglong2 *hole_list, unsigned long long *result) {
+    __shared__ LdsParams prm;
+    __shared__ WaveLds<kEmit> wl[kWavesPerBlock];
+    __shared__ BlockLds bl;
+    {
+        const double *src = dprm->s_clash;
+        double *dst = prm.s_clash;
+        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
+        if (threadIdx.x == 0) {
+            prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
+            bl.alloc_state = (0xFFFFFFFFull << 32) | kUnitsPerChunk;
+        }
+        __syncthreads();
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long n = min(result[3], tg.defer_cap);
+    uint32_t rqlen = 0;
+    for (unsigned long long e0 = ((unsigned long long)blockIdx.x * kWavesPerBlock + wave) * 64ull; e0 < n; e0 += (unsigned long long)gridDim.x * kWavesPerBlock * 64ull) {
+        const bool act = e0 + lane < n;
+        const uint2 ent = act ? tg.defer_list[e0 + lane] : make_uint2(0u, 0u);
+        process_batch<kEmit, true>(in, prm, so, wl[wave], bl, ent, act, 0ull, 0u, rqlen, tg, result, lane);
+    }
+    emit_epilogue(wl, bl, rqlen, tg, hole_list + blockIdx.x, result, wave, lane);
 }
 
 __global__ void k_finish(const GridParams *g, const unsigned long long *task_base, unsigned long long *result, unsigned long long capacity,
@@ -429,7 +487,7 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
     auto P1 = [&]() { if (prof) prof->end(st); };
     if (prof) prof->n = 0;
     P0("grid_bounds");
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, ws.bounds, ws.result);
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, ws.bounds, ws.result, ws.task_ctr);
     if (n) hipLaunchKernelGGL(k_bounds, dim3(nb < 256 ? nb : 256), dim3(256), 0, st, in, ws.bounds);
     hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, (const Bounds *)ws.bounds, ws.grid, ws.params, cutoff, ws.ncells_cap);
     P1();
@@ -452,11 +510,11 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
 
 // candidate pairs per task + their scan + total (result[0])
 void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out) {
-    EmitTarget none{nullptr, 0ull, nullptr, 0ull};
+    EmitTarget none{nullptr, 0ull, nullptr, 0ull, nullptr, 0ull};
     if (prof) prof->begin("pairs_count", st);
-    hipLaunchKernelGGL(k_pairs<kCountTasks>, dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+    hipLaunchKernelGGL((k_pairs<kCountTasks, true>), dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
                        (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
-                       (const unsigned long long *)ws.task_base, none, ws.hole_list, ws.result);
+                       (const unsigned long long *)ws.task_base, none, ws.hole_list, ws.task_ctr, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_scan", st); }
     launch_scan<unsigned long long>(ws.task_count, &ws.grid->n_tasks, ws.scan_tmp64, ws.task_base, st);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, (const GridParams *)ws.grid, (const unsigned long long *)ws.task_base, ws.result,
@@ -466,23 +524,27 @@ void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profi
 
 // ordered fill: needs launch_count first
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
-    EmitTarget tg{out, capacity, nullptr, 0ull};
+    EmitTarget tg{out, capacity, nullptr, 0ull, nullptr, 0ull};
     if (prof) prof->begin("pairs_fill", st);
-    hipLaunchKernelGGL(k_pairs<kFillOrdered>, dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+    hipLaunchKernelGGL((k_pairs<kFillOrdered, true>), dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
                        (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
-                       (const unsigned long long *)ws.task_base, tg, ws.hole_list, ws.result);
+                       (const unsigned long long *)ws.task_base, tg, ws.hole_list, ws.task_ctr, ws.result);
     if (prof) prof->end(st);
 }
 
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
-    EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap};
+    EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t nb = blocks_for(in.n, kEmitBlocks);
     if (prof) prof->begin("pairs_emit", st);
-    hipLaunchKernelGGL(k_pairs<kEmit>, dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
+    hipLaunchKernelGGL((k_pairs<kEmit, false>), dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
                        (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,
-                       ws.result);
+                       ws.task_ctr, ws.result);
+    if (prof) { prof->end(st); prof->begin("pairs_deferred", st); }
+    hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg,
+                       ws.hole_list + nb, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_fixup", st); }
-    hipLaunchKernelGGL(k_fixup, dim3(64), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, nb, (const GridParams *)ws.grid, tg, ws.result);
+    hipLaunchKernelGGL(k_fixup, dim3(64), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, nb + kDeferBlocks, (const GridParams *)ws.grid, tg,
+                       ws.result);
     if (prof) prof->end(st);
 }
