@@ -38,12 +38,6 @@ struct GridParams {
     uint32_t pad;
 };
 
-struct Bounds {           // order-preserving u64 encodings of f64 min/max, reduced with atomics
-    unsigned long long mn[3], mx[3];
-    uint32_t n_models;    // max model ordinal + 1
-    uint32_t bad;
-};
-
 // Device view of the caller's SoA (all device pointers).
 struct DevAtoms {
     uint32_t n;
@@ -68,7 +62,8 @@ struct Sorted {
 };
 
 struct Workspace {
-    Bounds *bounds;
+    double *partials;         // k_bounds: [256][8] per-block partial results
+    uint32_t *tickets;        // self-resetting arrival counters: [0] bounds, [1] cell scan, [2] pair scan
     GridParams *grid;
     DevParams *params;
     uint32_t *cell_of_atom;   // n
@@ -105,7 +100,7 @@ struct Profiler {
 };
 
 // Launch wrappers (kernels.hip / pairs.inl).  All asynchronous on `st`.
-void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff);
+void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered);
 void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out);
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);

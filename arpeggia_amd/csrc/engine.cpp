@@ -123,7 +123,7 @@ static void free_workspace(arp_context *ctx) {
 
 static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     Workspace &w = ctx->ws;
-    if (w.n_cap >= n && w.bounds) return ARP_OK;
+    if (w.n_cap >= n && w.grid) return ARP_OK;
     if (n >= 0xFFFFFFF0ull) { set_error("too many atoms for 32-bit indices"); return ARP_ERR_BAD_INPUT; }
     (void)hipStreamSynchronize(ctx->stream);
     free_workspace(ctx);
@@ -131,17 +131,20 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     uint64_t ccap = std::min<uint64_t>(8 * cap + 65536, 0xFFFFFFF0ull);
     arp_status s;
 #define A(ptr, cnt) if ((s = dev_alloc(ctx, &(ptr), (cnt))) != ARP_OK) { free_workspace(ctx); return s; }
-    A(w.bounds, 1); A(w.grid, 1); A(w.params, 1);
+    A(w.partials, 1024 * 8); A(w.tickets, 4); A(w.grid, 1); A(w.params, 1);
     A(w.cell_of_atom, cap); A(w.rank_of_atom, cap); A(w.cell_count, ccap + 1); A(w.cell_start, ccap + 1);
     A(w.perm, cap); A(w.slot_cell, cap);
     A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.hinfo, cap);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
-    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);
+    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 1024); A(w.task_ctr, 32); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
     w.defer_cap = std::max<uint64_t>(8 * cap, 1u << 20); A(w.defer_list, w.defer_cap);
 #undef A
     w.n_cap = (uint32_t)cap;
     w.ncells_cap = (uint32_t)ccap;
+    // self-cleaning state: the kernels leave these zeroed for the next call
+    HIP_TRY(hipMemsetAsync(w.cell_count, 0, (ccap + 1) * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(w.tickets, 0, 4 * sizeof(uint32_t), ctx->stream));
     return ARP_OK;
 }
 
@@ -279,6 +282,7 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
 
 static arp_status flags_to_status(unsigned long long flags) {
     if (flags & 4ull) { set_error("non-finite atom coordinate"); return ARP_ERR_BAD_INPUT; }
+    if (flags & 16ull) { set_error("internal error: inconsistent hole plan in k_fixup"); return ARP_ERR_HIP; }
     if (flags & 8ull) { set_error("deferred-probe list overflow; rerun with ARP_FLAG_DETERMINISTIC"); return ARP_ERR_CAPACITY; }
     if (flags & 2ull) { set_error("CYS SG..SG covalent pair whose residue has no CB (the reference panics in is_disulfide, vdw.rs:58)"); return ARP_ERR_BAD_INPUT; }
     return ARP_OK;
@@ -297,7 +301,8 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
     if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
-    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff);
+    const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0;
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered);
     if (!out || capacity == 0) {
         launch_count(d, ctx->ws, ctx->stream, prof, 0, true);  // size query: reports ARP_ERR_CAPACITY + the count
     } else if (params->flags & ARP_FLAG_DETERMINISTIC) {
@@ -342,7 +347,7 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
     // count pass -> exact output size -> ordered fill or single-pass emit
-    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff);
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, (params->flags & ARP_FLAG_DETERMINISTIC) != 0);
     launch_count(d, ctx->ws, ctx->stream, prof, 0, false);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));

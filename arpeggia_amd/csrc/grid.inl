@@ -1,0 +1,305 @@
+// Uniform-grid (cell list) construction.  Included by kernels.hip inside namespace arp.
+//
+//   k_bounds + k_setup   bounding box of the heavy atoms, then one block sizes the grid (no host round trip)
+//   k_cellid   cell of every atom + its arrival rank in the cell (one returning atomic per RUN of same-cell atoms in a wave)
+//   scan       cell_count -> cell_start (three launches; the last one also clears cell_count for the next call)
+//   k_place    emit mode: each atom writes its records straight to slot cell_start + arrival rank (coalesced reads)
+//   k_scatter + k_gather   ordered mode: slots inside a cell follow the atom index, so the emitted order is reproducible
+
+// ---------------------------------------------------------------------------------------------- bounds + grid setup
+constexpr uint32_t kBoundsBlocks = 1024;
+
+DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, uint32_t n_models, uint32_t bad, GridParams *g, DevParams *prm,
+                      double cutoff, uint32_t ncells_cap) {
+    double lo[3], ext[3];
+    for (int k = 0; k < 3; k++) {
+        lo[k] = empty ? 0.0 : lo_in[k];
+        ext[k] = empty ? 0.0 : hi_in[k] - lo[k];
+        if (!(ext[k] >= 0.0) || !isfinite(ext[k])) ext[k] = 0.0;
+        if (!isfinite(lo[k])) lo[k] = 0.0;
+    }
+    const uint32_t nm = n_models ? n_models : 1u;
+    // edge slightly above the cutoff so that |dx| <= cutoff can never straddle two cell boundaries after rounding
+    double edge = cutoff * (1.0 + 1e-6);
+    if (!(edge > 1e-3)) edge = 1e-3;
+    double nx, ny, nz;
+    for (;;) {
+        nx = floor(ext[0] / edge) + 1.0; ny = floor(ext[1] / edge) + 1.0; nz = floor(ext[2] / edge) + 1.0;
+        if (nx * ny * (nz + 1.0) * (double)nm <= (double)ncells_cap) break;
+        edge *= 1.2599210498948732;  // sparse / huge extents: coarser cells stay correct (edge >= cutoff)
+    }
+    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2];
+    g->inv_edge = 1.0 / edge;
+    g->nx = (uint32_t)nx; g->ny = (uint32_t)ny; g->nz = (uint32_t)nz;
+    g->nzt = nm * (g->nz + 1u);
+    g->ncells = g->nx * g->ny * g->nzt;
+    g->n_heavy = 0; g->n_tasks = 0;
+    g->bad = bad;
+    // f32 prefilter: relative coordinates carry <= 2^-24 * extent of rounding each; a 10x-safe bound on the
+    // induced error of dx^2+dy^2+dz^2 near the cutoff (derivation in DESIGN.md "Prefilter margin")
+    const double M = fmax(ext[0], fmax(ext[1], ext[2])) + edge;
+    const double margin = 4e-6 * (prm->r2 + fabs(cutoff) * M) + 1e-6;
+    g->prefilter_margin = (float)margin;
+    prm->r2f = __double2float_ru(prm->r2 + margin);
+}
+
+// Bounding box in two launches: per-block partial results with plain stores, then one block reduces them and sizes the grid.
+// (A single launch with an arrival ticket was measured 2-3x slower: the per-block device-scope atomics / write-through
+// stores cost more than the extra launch.)  partials: [kBoundsBlocks][8] doubles = {min xyz, max xyz, models, bad}.
+struct BoxAcc {
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t models = 0, bad = 0;
+};
+DEVFN void box_block_reduce(BoxAcc &a, double (*s_mn)[3], double (*s_mx)[3], uint32_t *s_models, uint32_t *s_bad) {
+    for (int off = 32; off; off >>= 1) {
+        for (int k = 0; k < 3; k++) {
+            a.mn[k] = fmin(a.mn[k], __shfl_xor(a.mn[k], off));
+            a.mx[k] = fmax(a.mx[k], __shfl_xor(a.mx[k], off));
+        }
+        a.models = max(a.models, (uint32_t)__shfl_xor((int)a.models, off));
+        a.bad |= (uint32_t)__shfl_xor((int)a.bad, off);
+    }
+    const uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; k++) { s_mn[w][k] = a.mn[k]; s_mx[w][k] = a.mx[k]; }
+        s_models[w] = a.models; s_bad[w] = a.bad;
+    }
+    __syncthreads();
+    for (int k = 0; k < 3; k++) {
+        a.mn[k] = fmin(fmin(s_mn[0][k], s_mn[1][k]), fmin(s_mn[2][k], s_mn[3][k]));
+        a.mx[k] = fmax(fmax(s_mx[0][k], s_mx[1][k]), fmax(s_mx[2][k], s_mx[3][k]));
+    }
+    a.models = max(max(s_models[0], s_models[1]), max(s_models[2], s_models[3]));
+    a.bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+}
+
+__global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
+    __shared__ double s_mn[4][3], s_mx[4][3];
+    __shared__ uint32_t s_models[4], s_bad[4];
+    BoxAcc acc;
+    // Four independent atoms per trip, loaded UNCONDITIONALLY from a clamped index: predicated loads make hipcc wait for
+    // each attr word before issuing the next atom's loads, which turns the loop into serial round trips.
+    const uint32_t stride = gridDim.x * blockDim.x, last = in.n ? in.n - 1u : 0u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < in.n; i0 += 4u * stride) {
+        double p[4][3];
+        uint32_t at[4], md[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = min(i0 + (uint32_t)u * stride, last);
+            at[u] = in.attr[i]; md[u] = (uint32_t)in.model[i];
+            p[u][0] = in.x[i]; p[u][1] = in.y[i]; p[u][2] = in.z[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool use = (i0 + (uint32_t)u * stride < in.n) & !(at[u] & ARP_ATTR_H);
+            for (int k = 0; k < 3; k++) {
+                acc.bad |= (use & !isfinite(p[u][k])) ? 1u : 0u;
+                acc.mn[k] = use ? fmin(acc.mn[k], p[u][k]) : acc.mn[k];
+                acc.mx[k] = use ? fmax(acc.mx[k], p[u][k]) : acc.mx[k];
+            }
+            acc.models = use ? max(acc.models, md[u] + 1u) : acc.models;
+        }
+    }
+    box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
+    if (threadIdx.x == 0) {
+        double *p = partials + 8 * blockIdx.x;
+        for (int k = 0; k < 3; k++) { p[k] = acc.mn[k]; p[3 + k] = acc.mx[k]; }
+        p[6] = (double)acc.models; p[7] = (double)acc.bad;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t n_partials, GridParams *g, DevParams *prm, double cutoff,
+                                               uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr) {
+    __shared__ double s_mn[4][3], s_mx[4][3];
+    __shared__ uint32_t s_models[4], s_bad[4];
+    if (threadIdx.x < 24) task_ctr[threadIdx.x] = 0;  // per-call state of the later kernels
+    if (threadIdx.x < 4) result[threadIdx.x] = 0;
+    BoxAcc acc;
+    for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {
+        const double *p = partials + 8 * b;
+        for (int k = 0; k < 3; k++) { acc.mn[k] = fmin(acc.mn[k], p[k]); acc.mx[k] = fmax(acc.mx[k], p[3 + k]); }
+        acc.models = max(acc.models, (uint32_t)p[6]); acc.bad |= (uint32_t)p[7];
+    }
+    box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
+    if (threadIdx.x == 0) grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad, g, prm, cutoff, ncells_cap);
+}
+
+DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
+    double fx = (x - g.ox) * g.inv_edge, fy = (y - g.oy) * g.inv_edge, fz = (z - g.oz) * g.inv_edge;
+    uint32_t cx = (fx >= 0.0) ? (uint32_t)fmin(fx, 4.0e9) : 0u;  // NaN -> 0
+    uint32_t cy = (fy >= 0.0) ? (uint32_t)fmin(fy, 4.0e9) : 0u;
+    uint32_t cz = (fz >= 0.0) ? (uint32_t)fmin(fz, 4.0e9) : 0u;
+    cx = min(cx, g.nx - 1u); cy = min(cy, g.ny - 1u); cz = min(cz, g.nz - 1u);
+    uint32_t layer = model * (g.nz + 1u) + cz;  // every model owns a z slab followed by one empty layer
+    layer = min(layer, g.nzt - 1u);
+    return (layer * g.ny + cy) * g.nx + cx;
+}
+
+// Cell of every atom and its arrival rank inside the cell.  Atoms that are consecutive in the input and fall into the same
+// cell (the common case: a residue, a lattice column) share ONE returning atomic issued by the head of the run; a
+// scattered-address atomic wave-instruction costs about a microsecond, so fewer of them is what matters here.
+__global__ __launch_bounds__(256) void k_cellid(DevAtoms in, const GridParams *gp, uint32_t *cell_of_atom, uint32_t *rank_of_atom,
+                                                uint32_t *cell_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t c = ARP_NONE;
+    if (i < in.n && !(in.attr[i] & ARP_ATTR_H)) {
+        GridParams g = *gp;
+        c = cell_index(g, in.x[i], in.y[i], in.z[i], in.model[i]);
+    }
+    const uint32_t prev = (uint32_t)__shfl_up((int)c, 1);
+    const bool head = (c != ARP_NONE) && (lane == 0 || prev != c);
+    const unsigned long long heads = __ballot(head), live = __ballot(c != ARP_NONE);
+    uint32_t r = 0;
+    if (c != ARP_NONE) {
+        // run = [start, end): start = last head at or below this lane, end = next head (or next dead lane) above it
+        const unsigned long long below = heads & ((2ull << lane) - 1ull);
+        const uint32_t start = 63u - (uint32_t)__clzll((long long)below);
+        const unsigned long long stop = (heads | ~live) >> start >> 1;  // boundaries above the run head
+        const uint32_t len = stop ? (uint32_t)__ffsll((long long)stop) : 64u - start;
+        uint32_t base = 0;
+        if (head) base = atomicAdd(&cell_count[c], len);
+        r = (uint32_t)__shfl((int)base, (int)start) + (lane - start);
+    }
+    if (i < in.n) { cell_of_atom[i] = c; rank_of_atom[i] = r; }
+}
+
+// ---------------------------------------------------------------------------------------------- scan
+// Exclusive scan of in[0..n) (n read from device memory) into out[0..n], out[n] = total, over a fixed 1024-block
+// decomposition so that no host knowledge of n is needed.  Three launches: per-block sums, their scan, the per-block
+// scans (a fused arrival-ticket variant was measured slower).  ZERO_IN clears the input behind itself (cell_count is
+// ready for the next call); FINISH also publishes the pair total and the status flags.
+constexpr uint32_t kScanBlocks = 1024, kScanThreads = 256;
+
+template <typename TOut>
+DEVFN TOut block_exclusive_scan(TOut v, TOut *total, TOut *lds /* [kScanThreads/64 + 1] */) {
+    TOut inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        TOut t = __shfl_up(inc, off);
+        if ((threadIdx.x & 63) >= (uint32_t)off) inc += t;
+    }
+    uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) lds[w] = inc;
+    __syncthreads();
+    TOut wave_off = 0, tot = 0;
+    for (uint32_t k = 0; k < kScanThreads / 64; k++) { TOut s = lds[k]; if (k < w) wave_off += s; tot += s; }
+    *total = tot;
+    return wave_off + inc - v;
+}
+
+template <typename TOut>
+__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t *in, const uint32_t *n_ptr, TOut *tmp) {
+    __shared__ TOut lds[kScanThreads / 64 + 1];
+    const uint32_t n = *n_ptr;
+    const uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
+    const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
+    TOut s = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kScanThreads) s += in[i];
+    TOut tot;
+    block_exclusive_scan<TOut>(s, &tot, lds);
+    if (threadIdx.x == 0) tmp[blockIdx.x] = tot;
+}
+template <typename TOut>
+__global__ __launch_bounds__(kScanThreads) void k_scan_tmp(TOut *tmp) {  // tmp[kScanBlocks] receives the grand total
+    __shared__ TOut lds[kScanThreads / 64 + 1];
+    TOut carry = 0;
+    for (uint32_t base = 0; base < kScanBlocks; base += kScanThreads) {
+        TOut v = tmp[base + threadIdx.x], tot;
+        TOut ex = block_exclusive_scan<TOut>(v, &tot, lds);
+        tmp[base + threadIdx.x] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tmp[kScanBlocks] = carry;
+}
+
+template <typename TOut, bool ZERO_IN, bool FINISH>
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const uint32_t *n_ptr, const TOut *tmp, TOut *out, const GridParams *g,
+                                                             unsigned long long *result, unsigned long long capacity, int have_out) {
+    __shared__ TOut lds[kScanThreads / 64 + 1];
+    const uint32_t n = *n_ptr;
+    const uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
+    const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
+    TOut carry = tmp[blockIdx.x];
+    for (uint32_t base = lo; base < hi; base += kScanThreads) {
+        const uint32_t i = base + threadIdx.x;
+        TOut v = (i < hi) ? (TOut)in[i] : (TOut)0, tot;
+        TOut ex = block_exclusive_scan<TOut>(v, &tot, lds);
+        if (i < hi) { out[i] = carry + ex; if (ZERO_IN) in[i] = 0; }
+        carry += tot;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const TOut total = tmp[kScanBlocks];
+        out[n] = total;
+        if (FINISH) {  // the pair-count scan also publishes the result word and the status flags
+            result[0] = (unsigned long long)total;
+            if (have_out && (unsigned long long)total > capacity) result[1] |= 1ull;
+            if (g->bad) result[1] |= 4ull;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- sort into cells
+constexpr uint32_t kAttrResHasH = 0x80000000u;  // internal: the atom's residue carries hydrogens (set when the atom is placed)
+
+DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so, uint32_t i, uint32_t c, uint32_t d) {
+    const double x = in.x[i], y = in.y[i], z = in.z[i];
+    so.rec[d] = make_float4((float)(x - gp->ox), (float)(y - gp->oy), (float)(z - gp->oz), __uint_as_float(c));
+    Fat f;
+    f.x = x; f.y = y; f.z = z;
+    f.attr = in.attr[i] & ~kAttrResHasH; f.res_ord = in.res_ord[i]; f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i;
+    // Resolve the residue -> hydrogens indirection once per atom: the pair kernel touches the hydrogen tables only for
+    // donors whose residue really carries hydrogens (hbond.rs:38-42), with no dependent loads on the common path.
+    uint2 hi = make_uint2(0u, 0u);
+    if (in.n_res) {
+        const uint32_t r = in.res_id[i];
+        hi.x = in.res_h_ptr[r]; hi.y = in.res_h_ptr[r + 1];
+        if (hi.x < hi.y) f.attr |= kAttrResHasH;
+    }
+    so.hinfo[d] = hi;
+    so.fat[d] = f;
+}
+
+// Emit mode: slot = cell_start + arrival rank.  Reads are coalesced (input order), each atom writes its 72 bytes once.
+__global__ __launch_bounds__(256) void k_place(DevAtoms in, GridParams *gp, const uint32_t *cell_start, const uint32_t *cell_of_atom,
+                                               const uint32_t *rank_of_atom, Sorted so) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { const uint32_t n_heavy = cell_start[gp->ncells]; gp->n_heavy = n_heavy; gp->n_tasks = (n_heavy + 63u) / 64u; }
+    if (i >= in.n) return;
+    const uint32_t c = cell_of_atom[i];
+    if (c == ARP_NONE) return;
+    place_atom(in, gp, so, i, c, cell_start[c] + rank_of_atom[i]);
+}
+
+__global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *cell_of_atom, const uint32_t *rank_of_atom,
+                                                 const uint32_t *cell_start, uint32_t *perm, uint32_t *slot_cell) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = cell_of_atom[i];
+    if (c == ARP_NONE) return;
+    uint32_t p = cell_start[c] + rank_of_atom[i];
+    perm[p] = i;
+    slot_cell[p] = c;
+}
+
+// Ordered mode: final slot = cell_start + rank of the atom index inside its cell, so the sorted order (and therefore the
+// order of the emitted pairs) does not depend on the arrival order of the atomics in k_cellid.
+__global__ __launch_bounds__(256) void k_gather(DevAtoms in, GridParams *gp, const uint32_t *cell_start, const uint32_t *perm,
+                                                const uint32_t *slot_cell, Sorted so) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ncells = gp->ncells;
+    uint32_t n_heavy = cell_start[ncells];
+    if (p == 0) { gp->n_heavy = n_heavy; gp->n_tasks = (n_heavy + 63u) / 64u; }
+    if (p >= n_heavy) return;
+    uint32_t c = slot_cell[p], i = perm[p];
+    uint32_t s = cell_start[c], e = cell_start[c + 1], rank = 0;
+    for (uint32_t q = s; q < e; q += 4) {  // four independent loads per trip: the loop is latency-bound otherwise
+        const uint32_t u0 = perm[q], u1 = (q + 1 < e) ? perm[q + 1] : 0xFFFFFFFFu, u2 = (q + 2 < e) ? perm[q + 2] : 0xFFFFFFFFu,
+                       u3 = (q + 3 < e) ? perm[q + 3] : 0xFFFFFFFFu;
+        rank += (u0 < i) + (u1 < i) + (u2 < i) + (u3 < i);
+    }
+    place_atom(in, gp, so, i, c, s + rank);
+}

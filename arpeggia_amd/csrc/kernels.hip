@@ -1,8 +1,8 @@
 // HIP kernels of the contact engine, written for gfx950 (MI355X, wave64) only.
 //
 // Pipeline (all on one stream, no host round trip):
-//   k_init -> k_bounds -> k_setup -> k_zero_cells -> k_cellid -> scan(cell_count) -> k_scatter -> k_gather
-//   -> k_pairs<COUNT> -> scan(task_count) -> k_finish -> k_pairs<FILL>
+//   k_bounds (+ grid setup) -> k_cellid -> scan(cell_count) -> k_place | k_scatter + k_gather          (grid.inl)
+//   -> k_pairs<emit> -> k_pairs_deferred -> k_fixup   |   k_pairs<count> -> scan -> k_pairs<fill>    (pairs.inl)
 // It replaces the reference's R*-tree build + serial neighbour walk + rayon classification
 // (src/contacts/complex.rs:189-299) with a uniform-grid cell list and a count/scan/fill pair emitter whose
 // output order is deterministic.  Decisions are made in f64 with the reference's operation order and no FMA
@@ -42,233 +42,9 @@ DEVFN uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 DEVFN void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-constexpr uint32_t kAttrResHasH = 0x80000000u;  // internal: the atom's residue carries hydrogens (set by k_gather)
 
-// ---------------------------------------------------------------------------------------------- grid build
-__global__ void k_init(Bounds *b, unsigned long long *result, uint32_t *task_ctr) {
-    if (threadIdx.x < 24) task_ctr[threadIdx.x] = 0;
-    if (threadIdx.x < 3) { b->mn[threadIdx.x] = ~0ull; b->mx[threadIdx.x] = 0ull; }
-    if (threadIdx.x == 0) { b->n_models = 0; b->bad = 0; result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; }
-}
-
-// Bounding box of the heavy atoms: registers -> wave shuffles -> LDS -> one atomic set per block (<= 256 blocks).
-__global__ __launch_bounds__(256) void k_bounds(DevAtoms in, Bounds *b) {
-    __shared__ double s_mn[4][3], s_mx[4][3];
-    __shared__ uint32_t s_models[4], s_bad[4];
-    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    uint32_t models = 0, bad = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += gridDim.x * blockDim.x) {
-        if (in.attr[i] & ARP_ATTR_H) continue;
-        double p[3] = {in.x[i], in.y[i], in.z[i]};
-        for (int k = 0; k < 3; k++) {
-            if (!isfinite(p[k])) bad = 1;
-            mn[k] = fmin(mn[k], p[k]);
-            mx[k] = fmax(mx[k], p[k]);
-        }
-        models = max(models, (uint32_t)in.model[i] + 1u);
-    }
-    for (int off = 32; off; off >>= 1) {
-        for (int k = 0; k < 3; k++) {
-            mn[k] = fmin(mn[k], __shfl_xor(mn[k], off));
-            mx[k] = fmax(mx[k], __shfl_xor(mx[k], off));
-        }
-        models = max(models, (uint32_t)__shfl_xor((int)models, off));
-        bad |= (uint32_t)__shfl_xor((int)bad, off);
-    }
-    const uint32_t w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 3; k++) { s_mn[w][k] = mn[k]; s_mx[w][k] = mx[k]; }
-        s_models[w] = models; s_bad[w] = bad;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int k = threadIdx.x;
-        double a = fmin(fmin(s_mn[0][k], s_mn[1][k]), fmin(s_mn[2][k], s_mn[3][k]));
-        double c = fmax(fmax(s_mx[0][k], s_mx[1][k]), fmax(s_mx[2][k], s_mx[3][k]));
-        if (a <= c) { atomicMin(&b->mn[k], enc_f64(a)); atomicMax(&b->mx[k], enc_f64(c)); }
-    }
-    if (threadIdx.x == 3) {
-        atomicMax(&b->n_models, max(max(s_models[0], s_models[1]), max(s_models[2], s_models[3])));
-        if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) atomicOr(&b->bad, 1u);
-    }
-}
-
-__global__ void k_setup(const Bounds *b, GridParams *g, DevParams *prm, double cutoff, uint32_t ncells_cap) {
-    if (threadIdx.x | blockIdx.x) return;
-    double lo[3], ext[3];
-    bool empty = b->mn[0] == ~0ull;
-    for (int k = 0; k < 3; k++) {
-        lo[k] = empty ? 0.0 : dec_f64(b->mn[k]);
-        ext[k] = empty ? 0.0 : dec_f64(b->mx[k]) - lo[k];
-        if (!(ext[k] >= 0.0) || !isfinite(ext[k])) ext[k] = 0.0;
-        if (!isfinite(lo[k])) lo[k] = 0.0;
-    }
-    uint32_t nm = b->n_models ? b->n_models : 1u;
-    // edge slightly above the cutoff so that |dx| <= cutoff can never straddle two cell boundaries after rounding
-    double edge = cutoff * (1.0 + 1e-6);
-    if (!(edge > 1e-3)) edge = 1e-3;
-    double nx, ny, nz;
-    for (;;) {
-        nx = floor(ext[0] / edge) + 1.0; ny = floor(ext[1] / edge) + 1.0; nz = floor(ext[2] / edge) + 1.0;
-        if (nx * ny * (nz + 1.0) * (double)nm <= (double)ncells_cap) break;
-        edge *= 1.2599210498948732;  // sparse / huge extents: coarser cells stay correct (edge >= cutoff)
-    }
-    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2];
-    g->inv_edge = 1.0 / edge;
-    g->nx = (uint32_t)nx; g->ny = (uint32_t)ny; g->nz = (uint32_t)nz;
-    g->nzt = nm * (g->nz + 1u);
-    g->ncells = g->nx * g->ny * g->nzt;
-    g->n_heavy = 0; g->n_tasks = 0;
-    g->bad = b->bad;
-    // f32 prefilter: relative coordinates carry <= 2^-24 * extent of rounding each; a 10x-safe bound on the
-    // induced error of dx^2+dy^2+dz^2 near the cutoff (derivation in DESIGN.md "Prefilter margin")
-    double M = fmax(ext[0], fmax(ext[1], ext[2])) + edge;
-    double margin = 4e-6 * (prm->r2 + fabs(cutoff) * M) + 1e-6;
-    g->prefilter_margin = (float)margin;
-    prm->r2f = __double2float_ru(prm->r2 + margin);
-}
-
-__global__ __launch_bounds__(256) void k_zero_cells(const GridParams *g, uint32_t *cell_count) {
-    uint32_t n = g->ncells;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) cell_count[i] = 0;
-}
-
-DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
-    double fx = (x - g.ox) * g.inv_edge, fy = (y - g.oy) * g.inv_edge, fz = (z - g.oz) * g.inv_edge;
-    uint32_t cx = (fx >= 0.0) ? (uint32_t)fmin(fx, 4.0e9) : 0u;  // NaN -> 0
-    uint32_t cy = (fy >= 0.0) ? (uint32_t)fmin(fy, 4.0e9) : 0u;
-    uint32_t cz = (fz >= 0.0) ? (uint32_t)fmin(fz, 4.0e9) : 0u;
-    cx = min(cx, g.nx - 1u); cy = min(cy, g.ny - 1u); cz = min(cz, g.nz - 1u);
-    uint32_t layer = model * (g.nz + 1u) + cz;  // every model owns a z slab followed by one empty layer
-    layer = min(layer, g.nzt - 1u);
-    return (layer * g.ny + cy) * g.nx + cx;
-}
-
-// One returning atomic per atom: the old value is the atom's arrival rank in its cell, so the scatter needs none.
-__global__ __launch_bounds__(256) void k_cellid(DevAtoms in, const GridParams *gp, uint32_t *cell_of_atom, uint32_t *rank_of_atom,
-                                                uint32_t *cell_count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= in.n) return;
-    GridParams g = *gp;
-    uint32_t c = ARP_NONE, r = 0;
-    if (!(in.attr[i] & ARP_ATTR_H)) {
-        c = cell_index(g, in.x[i], in.y[i], in.z[i], in.model[i]);
-        r = atomicAdd(&cell_count[c], 1u);
-    }
-    cell_of_atom[i] = c;
-    rank_of_atom[i] = r;
-}
-
-// ---------------------------------------------------------------------------------------------- scan
-// Exclusive scan of in[0..n) (n read from device memory) into out[0..n], out[n] = total.  Three launches over a
-// fixed 1024-block decomposition so that no host knowledge of n is needed.
-constexpr uint32_t kScanBlocks = 1024, kScanThreads = 256;
-
-template <typename TOut>
-DEVFN TOut block_exclusive_scan(TOut v, TOut *total, TOut *lds /* [kScanThreads/64 + 1] */) {
-    TOut inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        TOut t = __shfl_up(inc, off);
-        if ((threadIdx.x & 63) >= (uint32_t)off) inc += t;
-    }
-    uint32_t w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 63) lds[w] = inc;
-    __syncthreads();
-    TOut wave_off = 0, tot = 0;
-    for (uint32_t k = 0; k < kScanThreads / 64; k++) { TOut s = lds[k]; if (k < w) wave_off += s; tot += s; }
-    *total = tot;
-    return wave_off + inc - v;
-}
-
-template <typename TOut>
-__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t *in, const uint32_t *n_ptr, TOut *tmp) {
-    __shared__ TOut lds[kScanThreads / 64 + 1];
-    uint32_t n = *n_ptr;
-    uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
-    uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
-    TOut s = 0;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += kScanThreads) s += in[i];
-    TOut tot;
-    block_exclusive_scan<TOut>(s, &tot, lds);
-    if (threadIdx.x == 0) tmp[blockIdx.x] = tot;
-}
-template <typename TOut>
-__global__ __launch_bounds__(kScanThreads) void k_scan_tmp(TOut *tmp) {  // tmp[kScanBlocks] receives the grand total
-    __shared__ TOut lds[kScanThreads / 64 + 1];
-    TOut carry = 0;
-    for (uint32_t base = 0; base < kScanBlocks; base += kScanThreads) {
-        TOut v = tmp[base + threadIdx.x], tot;
-        TOut ex = block_exclusive_scan<TOut>(v, &tot, lds);
-        tmp[base + threadIdx.x] = carry + ex;
-        carry += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) tmp[kScanBlocks] = carry;
-}
-template <typename TOut>
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t *in, const uint32_t *n_ptr, const TOut *tmp, TOut *out) {
-    __shared__ TOut lds[kScanThreads / 64 + 1];
-    uint32_t n = *n_ptr;
-    uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
-    uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
-    TOut carry = tmp[blockIdx.x];
-    for (uint32_t base = lo; base < hi; base += kScanThreads) {
-        uint32_t i = base + threadIdx.x;
-        TOut v = (i < hi) ? (TOut)in[i] : (TOut)0, tot;
-        TOut ex = block_exclusive_scan<TOut>(v, &tot, lds);
-        if (i < hi) out[i] = carry + ex;
-        carry += tot;
-        __syncthreads();
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tmp[kScanBlocks];
-}
-
-// ---------------------------------------------------------------------------------------------- sort into cells
-__global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *cell_of_atom, const uint32_t *rank_of_atom,
-                                                 const uint32_t *cell_start, uint32_t *perm, uint32_t *slot_cell) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = cell_of_atom[i];
-    if (c == ARP_NONE) return;
-    uint32_t p = cell_start[c] + rank_of_atom[i];
-    perm[p] = i;
-    slot_cell[p] = c;
-}
-
-// Final slot = cell_start + rank of the atom index inside its cell: the sorted order (and therefore the order of
-// the emitted pairs) does not depend on the arrival order of the atomics above.
-__global__ __launch_bounds__(256) void k_gather(DevAtoms in, GridParams *gp, const uint32_t *cell_start, const uint32_t *perm,
-                                                const uint32_t *slot_cell, Sorted so) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ncells = gp->ncells;
-    uint32_t n_heavy = cell_start[ncells];
-    if (p == 0) { gp->n_heavy = n_heavy; gp->n_tasks = (n_heavy + 63u) / 64u; }
-    if (p >= n_heavy) return;
-    uint32_t c = slot_cell[p], i = perm[p];
-    uint32_t s = cell_start[c], e = cell_start[c + 1], rank = 0;
-    for (uint32_t q = s; q < e; q += 4) {  // four independent loads per trip: the loop is latency-bound otherwise
-        const uint32_t u0 = perm[q], u1 = (q + 1 < e) ? perm[q + 1] : 0xFFFFFFFFu, u2 = (q + 2 < e) ? perm[q + 2] : 0xFFFFFFFFu,
-                       u3 = (q + 3 < e) ? perm[q + 3] : 0xFFFFFFFFu;
-        rank += (u0 < i) + (u1 < i) + (u2 < i) + (u3 < i);
-    }
-    uint32_t d = s + rank;
-    double x = in.x[i], y = in.y[i], z = in.z[i];
-    so.rec[d] = make_float4((float)(x - gp->ox), (float)(y - gp->oy), (float)(z - gp->oz), __uint_as_float(c));
-    Fat f;
-    f.x = x; f.y = y; f.z = z;
-    f.attr = in.attr[i] & ~kAttrResHasH; f.res_ord = in.res_ord[i]; f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i;
-    // Resolve the residue -> hydrogens indirection once per atom: the pair kernel touches the hydrogen tables only for
-    // donors whose residue really carries hydrogens (hbond.rs:38-42), with no dependent loads on the common path.
-    uint2 hi = make_uint2(0u, 0u);
-    if (in.n_res) {
-        const uint32_t r = in.res_id[i];
-        hi.x = in.res_h_ptr[r]; hi.y = in.res_h_ptr[r + 1];
-        if (hi.x < hi.y) f.attr |= kAttrResHasH;
-    }
-    so.hinfo[d] = hi;
-    so.fat[d] = f;
-}
+// ---------------------------------------------------------------------------------------------- grid build, scan, sort
+#include "grid.inl"
 
 // ---------------------------------------------------------------------------------------------- per-pair rules
 struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB)

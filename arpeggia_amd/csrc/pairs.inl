@@ -26,7 +26,7 @@ constexpr int kQueue = 128;
 constexpr uint32_t kChunk = 256;            // neighbour records per staged chunk (4 KB)
 constexpr uint32_t kBlock = 16;             // prefilter tests per lane between two compaction steps
 constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
-constexpr uint32_t kEmitBlocks = 896;       // emit mode: 3.5 blocks per CU; with the 128 deferred blocks <= 1024 holes (one k_fixup thread each)
+constexpr uint32_t kEmitBlocks = 880;       // emit mode: ~3.5 blocks per CU; with the 128 deferred blocks < 1024 holes (one k_fixup thread each)
 constexpr uint32_t kGrab = 2;              // wave-tasks drawn per atomic
 constexpr uint32_t kUnit = 64;              // records per flush = one wave-wide 16-byte store
 constexpr uint32_t kUnitsPerChunk = 32;     // 2048 records per global allocation
@@ -358,91 +358,73 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
     emit_epilogue(wl, bl, rqlen, tg, hole_list + blockIdx.x, result, wave, lane);
 }
 
-__global__ void k_finish(const GridParams *g, const unsigned long long *task_base, unsigned long long *result, unsigned long long capacity,
-                         int have_out) {
-    if (threadIdx.x | blockIdx.x) return;
-    unsigned long long total = task_base[g->n_tasks];
-    result[0] = total;
-    if (have_out && total > capacity) result[1] |= 1ull;
-    if (g->bad) result[1] |= 4ull;
-}
-
 // Close the holes of the emit pass: with R = records reserved and P = R - sum(holes) valid ones, every hole slot below P
-// is filled with a valid record from [P, R).  Each block rebuilds the (tiny) plan in LDS: sort <= 1024 holes by start,
-// prefix sums of the hole parts below P and of the valid stretches above P, then a grid-stride copy.
-constexpr uint32_t kFixThreads = 1024;
+// is filled with a valid record from [P, R).  No sorting is needed: a hole is the tail of ONE 2048-record chunk, so the
+// valid records above P are described by a per-chunk table over the <= n_holes + 1 chunks that [P, R) spans, and the
+// hole slots below P by the holes themselves in any order.  Each block rebuilds that (tiny) plan in LDS -- two
+// 1024-wide scans -- and then takes part in a grid-stride copy.
+constexpr uint32_t kFixThreads = 1024;       // >= number of holes + 1
+constexpr uint32_t kChunkRecords = kUnit * kUnitsPerChunk;
+DEVFN unsigned long long scan1024_u64(unsigned long long v, unsigned long long *red, unsigned long long *total) {
+    const uint32_t i = threadIdx.x;
+    unsigned long long inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(inc, off);
+        if ((i & 63) >= (uint32_t)off) inc += t;
+    }
+    __syncthreads();
+    if ((i & 63) == 63) red[i >> 6] = inc;
+    __syncthreads();
+    unsigned long long before = 0, tot = 0;
+    for (uint32_t k = 0; k < kFixThreads / 64; k++) { if (k < (i >> 6)) before += red[k]; tot += red[k]; }
+    *total = tot;
+    return before + inc - v;  // exclusive
+}
 __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_list, uint32_t n_holes, const GridParams *g, EmitTarget tg,
                                                        unsigned long long *result) {
-    __shared__ unsigned long long hs[kFixThreads], he[kFixThreads];      // sorted holes [hs, he)
-    __shared__ unsigned long long fpre[kFixThreads + 1], tpre[kFixThreads + 2], tstart[kFixThreads + 1];
-    __shared__ unsigned long long red[kFixThreads / 64], red2[kFixThreads / 64];
+    __shared__ unsigned long long fstart[kFixThreads], fpre[kFixThreads + 1];   // hole parts below P, any order
+    __shared__ unsigned long long tstart[kFixThreads], tpre[kFixThreads + 1];   // valid stretch of each chunk of [P, R)
+    __shared__ unsigned int tlen[kFixThreads];
+    __shared__ unsigned long long red[kFixThreads / 64];
     const uint32_t i = threadIdx.x;
-    {
-        ulonglong2 h = (i < n_holes) ? hole_list[i] : make_ulonglong2(0ull, 0ull);
-        hs[i] = h.y ? h.x : ~0ull;  // empty holes sort last
-        he[i] = h.y ? h.x + h.y : ~0ull;
-    }
-    __syncthreads();
-    for (uint32_t k = 2; k <= kFixThreads; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t p = i ^ j;
-            if (p > i) {
-                const bool up = (i & k) == 0;
-                const unsigned long long a = hs[i], b = hs[p];
-                if ((a > b) == up) { hs[i] = b; hs[p] = a; const unsigned long long t = he[i]; he[i] = he[p]; he[p] = t; }
-            }
-            __syncthreads();
-        }
-    // totals
+    const ulonglong2 h = (i < n_holes) ? hole_list[i] : make_ulonglong2(0ull, 0ull);
     const unsigned long long R = result[2] * kUnit;
-    unsigned long long len = (hs[i] != ~0ull) ? he[i] - hs[i] : 0ull;
-    for (int off = 32; off; off >>= 1) len += __shfl_xor(len, off);
-    if ((i & 63) == 0) red[i >> 6] = len;
-    __syncthreads();
-    unsigned long long holes_total = 0;
-    for (uint32_t k = 0; k < kFixThreads / 64; k++) holes_total += red[k];
+    unsigned long long holes_total;
+    scan1024_u64(h.y, red, &holes_total);
     const unsigned long long P = R - holes_total;
-    // front part of hole i, and the valid stretch that FOLLOWS hole i-1 / precedes hole i (i = 0..n, n = real holes)
-    const bool real = hs[i] != ~0ull;
-    const unsigned long long f_len = (real && hs[i] < P) ? ((he[i] < P ? he[i] : P) - hs[i]) : 0ull;
-    const unsigned long long prev_end = (i == 0) ? 0ull : (hs[i - 1] != ~0ull ? he[i - 1] : R);
-    const unsigned long long next_start = real ? hs[i] : R;
-    const unsigned long long t_s = prev_end > P ? prev_end : P, t_e = next_start > P ? next_start : P;
-    const unsigned long long t_len = (i == 0 || hs[i - 1] != ~0ull) && t_e > t_s ? t_e - t_s : 0ull;  // one stretch past the last real hole, none after
-    tstart[i] = t_s;
-    // two 1024-wide exclusive scans (wave shuffles + one pass over the 16 wave totals)
-    unsigned long long fi = f_len, ti = t_len;
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long a = __shfl_up(fi, off), b = __shfl_up(ti, off);
-        if ((i & 63) >= (uint32_t)off) { fi += a; ti += b; }
+    // tail chunks: chunk c0 + i, valid part = [max(chunk base, P), chunk end) minus the chunk's hole (set below)
+    const unsigned long long c0 = P / kChunkRecords, n_tail = R / kChunkRecords - c0;  // R is a multiple of the chunk size; n_tail <= n_holes + 1
+    {
+        const unsigned long long cb = (c0 + i) * kChunkRecords;
+        const unsigned long long ts = cb > P ? cb : P;
+        tstart[i] = ts;
+        tlen[i] = (i < n_tail) ? (unsigned int)(cb + kChunkRecords - ts) : 0u;
     }
     __syncthreads();
-    if ((i & 63) == 63) { red[i >> 6] = fi; red2[i >> 6] = ti; }
-    __syncthreads();
-    unsigned long long fo = 0, to = 0, ftot = 0, ttot = 0;
-    for (uint32_t k = 0; k < kFixThreads / 64; k++) { if (k < (i >> 6)) { fo += red[k]; to += red2[k]; } ftot += red[k]; ttot += red2[k]; }
-    fpre[i] = fo + fi - f_len; tpre[i] = to + ti - t_len;
-    if (i == 0) {
-        fpre[kFixThreads] = ftot; tpre[kFixThreads] = ttot;
-        // the stretch after the LAST slot (only when all 1024 entries are real holes)
-        const unsigned long long pe = hs[kFixThreads - 1] != ~0ull ? he[kFixThreads - 1] : R;
-        const unsigned long long ts = pe > P ? pe : P;
-        tstart[kFixThreads] = ts;
-        tpre[kFixThreads + 1] = ttot + ((hs[kFixThreads - 1] != ~0ull && R > ts) ? R - ts : 0ull);
+    if (h.y && h.x / kChunkRecords >= c0) {  // this hole cuts the end off one tail chunk
+        const uint32_t j = (uint32_t)(h.x / kChunkRecords - c0);
+        tlen[j] = h.x > tstart[j] ? (unsigned int)(h.x - tstart[j]) : 0u;
     }
     __syncthreads();
-    const unsigned long long F = fpre[kFixThreads];
+    const unsigned long long f_len = (h.y && h.x < P) ? ((h.x + h.y < P ? h.x + h.y : P) - h.x) : 0ull;
+    unsigned long long F, T;
+    const unsigned long long fe = scan1024_u64(f_len, red, &F);
+    const unsigned long long te = scan1024_u64((unsigned long long)tlen[i], red, &T);
+    fstart[i] = h.x; fpre[i] = fe; tpre[i] = te;
+    if (i == 0) { fpre[kFixThreads] = F; tpre[kFixThreads] = T; }
+    __syncthreads();
     if (blockIdx.x == 0 && i == 0) {
         result[0] = P;
         if (P > tg.capacity) result[1] |= 1ull;
+        if (F != T) result[1] |= 16ull;  // internal consistency check of the plan
         if (g->bad) result[1] |= 4ull;
     }
-    if (P > tg.capacity) return;  // the caller's buffer cannot hold the table: report the size only
+    if (P > tg.capacity || F != T) return;  // the caller's buffer cannot hold the table: report the size only
     for (unsigned long long m = (unsigned long long)blockIdx.x * kFixThreads + i; m < F; m += (unsigned long long)gridDim.x * kFixThreads) {
-        uint32_t lo = 0, hi = kFixThreads;  // last k with fpre[k] <= m
+        uint32_t lo = 0, hi = kFixThreads;  // last k with fpre[k] <= m (zero-length entries are skipped by taking the last one)
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (fpre[mid] <= m) lo = mid; else hi = mid; }
-        const unsigned long long dst = hs[lo] + (m - fpre[lo]);
-        uint32_t lo2 = 0, hi2 = kFixThreads + 1;
+        const unsigned long long dst = fstart[lo] + (m - fpre[lo]);
+        uint32_t lo2 = 0, hi2 = kFixThreads;
         while (hi2 - lo2 > 1) { const uint32_t mid = (lo2 + hi2) >> 1; if (tpre[mid] <= m) lo2 = mid; else hi2 = mid; }
         const unsigned long long src = tstart[lo2] + (m - tpre[lo2]);
         uint4 *d = emit_slot(tg, dst, result);
@@ -465,11 +447,14 @@ void Profiler::end(hipStream_t st) {
     n++;
 }
 
-template <typename TOut>
-static void launch_scan(const uint32_t *in, const uint32_t *n_ptr, TOut *tmp, TOut *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_reduce<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, tmp);
+template <typename TOut, bool ZERO_IN, bool FINISH>
+static void launch_scan(uint32_t *in, const uint32_t *n_ptr, TOut *tmp, TOut *out, uint32_t *ticket, const Workspace &ws, unsigned long long capacity,
+                        bool have_out, hipStream_t st) {
+    (void)ticket;
+    hipLaunchKernelGGL(k_scan_reduce<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const uint32_t *)in, n_ptr, tmp);
     hipLaunchKernelGGL(k_scan_tmp<TOut>, dim3(1), dim3(kScanThreads), 0, st, tmp);
-    hipLaunchKernelGGL(k_scan_apply<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, (const TOut *)tmp, out);
+    hipLaunchKernelGGL((k_scan_apply<TOut, ZERO_IN, FINISH>), dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, (const TOut *)tmp, out,
+                       (const GridParams *)ws.grid, ws.result, capacity, have_out ? 1 : 0);
 }
 
 static uint32_t blocks_for(uint32_t n, uint32_t cap) {
@@ -480,31 +465,34 @@ static uint32_t blocks_for(uint32_t n, uint32_t cap) {
 
 unsigned long long emit_scratch_records() { return (unsigned long long)kFixThreads * (kUnitsPerChunk + 1) * kUnit; }
 
-void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff) {
+void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered) {
     const uint32_t n = in.n;
     const uint32_t nb = (n + 255) / 256;
     auto P0 = [&](const char *nm) { if (prof) prof->begin(nm, st); };
     auto P1 = [&]() { if (prof) prof->end(st); };
     if (prof) prof->n = 0;
     P0("grid_bounds");
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, ws.bounds, ws.result, ws.task_ctr);
-    if (n) hipLaunchKernelGGL(k_bounds, dim3(nb < 256 ? nb : 256), dim3(256), 0, st, in, ws.bounds);
-    hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, (const Bounds *)ws.bounds, ws.grid, ws.params, cutoff, ws.ncells_cap);
+    const uint32_t bb = nb < 1 ? 1 : (nb < kBoundsBlocks ? nb : kBoundsBlocks);
+    hipLaunchKernelGGL(k_bounds, dim3(bb), dim3(256), 0, st, in, ws.partials);
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, (const double *)ws.partials, bb, ws.grid, ws.params, cutoff, ws.ncells_cap, ws.result,
+                       ws.task_ctr);
     P1();
     P0("grid_count");
-    hipLaunchKernelGGL(k_zero_cells, dim3(1024), dim3(256), 0, st, (const GridParams *)ws.grid, ws.cell_count);
     if (n) hipLaunchKernelGGL(k_cellid, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
     P1();
     P0("grid_scan");
-    launch_scan<uint32_t>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, st);
+    launch_scan<uint32_t, true, false>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, ws.tickets + 1, ws, 0ull, false, st);
     P1();
     P0("grid_sort");
-    if (n) {
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, n, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.rank_of_atom,
-                           (const uint32_t *)ws.cell_start, ws.perm, ws.slot_cell);
+    if (ordered) {
+        if (n) hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, n, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.rank_of_atom,
+                                  (const uint32_t *)ws.cell_start, ws.perm, ws.slot_cell);
+        hipLaunchKernelGGL(k_gather, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.perm,
+                           (const uint32_t *)ws.slot_cell, ws.sorted);
+    } else {
+        hipLaunchKernelGGL(k_place, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.cell_of_atom,
+                           (const uint32_t *)ws.rank_of_atom, ws.sorted);
     }
-    hipLaunchKernelGGL(k_gather, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.perm,
-                       (const uint32_t *)ws.slot_cell, ws.sorted);
     P1();
 }
 
@@ -516,9 +504,7 @@ void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profi
                        (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
                        (const unsigned long long *)ws.task_base, none, ws.hole_list, ws.task_ctr, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_scan", st); }
-    launch_scan<unsigned long long>(ws.task_count, &ws.grid->n_tasks, ws.scan_tmp64, ws.task_base, st);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, (const GridParams *)ws.grid, (const unsigned long long *)ws.task_base, ws.result,
-                       capacity, have_out ? 1 : 0);
+    launch_scan<unsigned long long, false, true>(ws.task_count, &ws.grid->n_tasks, ws.scan_tmp64, ws.task_base, ws.tickets + 2, ws, capacity, have_out, st);
     if (prof) prof->end(st);
 }
 
@@ -544,7 +530,7 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg,
                        ws.hole_list + nb, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_fixup", st); }
-    hipLaunchKernelGGL(k_fixup, dim3(64), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, nb + kDeferBlocks, (const GridParams *)ws.grid, tg,
+    hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, nb + kDeferBlocks, (const GridParams *)ws.grid, tg,
                        ws.result);
     if (prof) prof->end(st);
 }
