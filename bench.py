@@ -78,6 +78,7 @@ def main():
     import arpeggia_amd as aa
     import synth
     from arpeggia_amd import _lib
+    from arpeggia_amd.sharding import reduce_job
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -146,12 +147,7 @@ def main():
             acc[k] = acc.get(k, 0.0) + v / args.profile_steps
     ctx.profile(False)
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    p = torch.tensor([float(n_pairs)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-    wall_max, pairs_all = float(t.item()), float(p.item())
+    wall_max, pairs_all = reduce_job(dist, dev, wall, n_pairs)  # max over ranks / sum over ranks; no data-path collective
 
     if rank == 0:
         dom = max(acc, key=acc.get)
