@@ -44,7 +44,7 @@ struct BlockLds {
 
 // mask = 2 * mask + (d2 <= r2f): one compare and one add-with-carry per prefilter test
 DEVFN void push_pass(uint32_t &mask, float d2, float r2f) {
-    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2f) : "vcc");
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2f) : "vcc");
 }
 
 struct EmitTarget {  // positions >= capacity spill into the engine's scratch so that a buffer of exactly P records suffices
@@ -276,11 +276,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
                     const uint32_t wbase = it0 < len ? off + it0 : 0u;
                     const float4 *win = w.nrec + wbase;
                     uint32_t mask = 0;
+                    // eight LDS reads in flight, then their eight tests: issued one by one, every test would pay the full LDS latency
 #pragma unroll
-                    for (uint32_t u = 0; u < kBlock; ++u) {
-                        const float4 r = win[u];
-                        const float dx = r.x - home.x, dy = r.y - home.y, dz = r.z - home.z;
-                        push_pass(mask, __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz)), r2f);
+                    for (uint32_t u0 = 0; u0 < kBlock; u0 += 8) {
+                        float rx[8], ry[8], rz[8];
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; }
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; ++u) {
+                            const float dx = rx[u] - home.x, dy = ry[u] - home.y, dz = rz[u] - home.z;
+                            push_pass(mask, __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz)), r2f);
+                        }
                     }
                     const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
                     if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);
@@ -521,7 +527,12 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
-    const uint32_t nb = blocks_for(in.n, kEmitBlocks);
+    static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 880)
+        const char *e = getenv("ARP_EMIT_BLOCKS");
+        const long v = e ? atol(e) : 0;
+        return (v >= 8 && v <= (long)kEmitBlocks) ? (uint32_t)v : kEmitBlocks;
+    }();
+    const uint32_t nb = blocks_for(in.n, emit_blocks);
     if (prof) prof->begin("pairs_emit", st);
     hipLaunchKernelGGL((k_pairs<kEmit, false>), dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
                        (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,
