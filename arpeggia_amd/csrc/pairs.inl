@@ -25,21 +25,19 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kQueue = 128;
 constexpr uint32_t kChunk = 256;            // neighbour records per staged chunk (4 KB)
 constexpr uint32_t kBlock = 16;             // prefilter tests per lane between two compaction steps
+constexpr uint32_t kReadAhead = 4;         // LDS reads in flight per lane in the prefilter (more costs a wave of occupancy in registers)
 constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
-constexpr uint32_t kEmitBlocks = 880;       // emit mode: ~3.5 blocks per CU; with the 128 deferred blocks < 1024 holes (one k_fixup thread each)
+constexpr uint32_t kEmitBlocks = 1280;      // emit mode: 5 blocks per CU; with the 128 deferred blocks < 2048 holes (k_fixup's capacity)
 constexpr uint32_t kGrab = 2;              // wave-tasks drawn per atomic
-constexpr uint32_t kUnit = 64;              // records per flush = one wave-wide 16-byte store
-constexpr uint32_t kUnitsPerChunk = 32;     // 2048 records per global allocation
+constexpr uint32_t kChunkRecords = 2048;    // records per global allocation (one device atomic each)
 
 template <int MODE>
 struct WaveLds {                                  // per-wave LDS working set
     float4 nrec[kChunk + kBlock];                 // f32 prefilter records of the staged chunk (+ kBlock: over-reads stay in bounds)
     uint2 queue[kQueue];                          // phase-1 survivors: (home slot, neighbour slot)
-    uint4 rq[MODE == kEmit ? 2 * kUnit : 1];      // emit mode: classified records waiting for a full unit
 };
 struct BlockLds {
-    unsigned long long alloc_state;               // current chunk: first unit << 32 | units handed out
-    uint32_t left[kWavesPerBlock];
+    unsigned long long alloc_state;               // emit mode: current chunk index << 32 | records handed out of it
 };
 
 // mask = 2 * mask + (d2 <= r2f): one compare and one add-with-carry per prefilter test
@@ -60,38 +58,36 @@ DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned lo
     return nullptr;
 }
 
-// Next free 64-record unit.  Called by a whole wave; lane 0 talks to the block's LDS bump allocator and, once per
-// kUnitsPerChunk units, to the global counter.  A wave that finds the chunk exhausted while another wave is already
-// refilling it sleeps until the new chunk is published (the refilling wave only waits for one returning atomic).
-DEVFN uint32_t alloc_unit(BlockLds &bl, unsigned long long *g_head, uint32_t lane) {
-    uint32_t unit = 0;
+// Output slots for the n (<= 64) valid records of a batch.  Called by a whole wave; lane 0 talks to the block's LDS bump
+// allocator (chunk index << 32 | records used) and, once per chunk, to the global chunk counter.  The one allocation that
+// crosses the end of the chunk takes the rest of it (n0 records at pos0), fetches the next chunk and continues there
+// (pos1); waves that arrive while it does so sleep on the LDS word until the new chunk is published.
+struct Slots { unsigned long long pos0, pos1; uint32_t n0; };
+DEVFN Slots alloc_records(BlockLds &bl, unsigned long long *g_head, uint32_t n, uint32_t lane) {
+    unsigned long long pos0 = 0, pos1 = 0;
+    uint32_t n0 = 0;
     if (lane == 0) {
         for (;;) {
-            const unsigned long long old = atomicAdd(&bl.alloc_state, 1ull);
-            const uint32_t used = (uint32_t)old, first = (uint32_t)(old >> 32);
-            if (used < kUnitsPerChunk) { unit = first + used; break; }
-            if (used == kUnitsPerChunk) {
-                const unsigned long long nb = atomicAdd(g_head, (unsigned long long)kUnitsPerChunk);
-                __hip_atomic_store(&bl.alloc_state, (nb << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                unit = (uint32_t)nb;
+            const unsigned long long old = atomicAdd(&bl.alloc_state, (unsigned long long)n);
+            const uint32_t used = (uint32_t)old, chunk = (uint32_t)(old >> 32);
+            if (used + n <= kChunkRecords) { pos0 = (unsigned long long)chunk * kChunkRecords + used; n0 = n; break; }
+            if (used <= kChunkRecords) {  // this allocation crosses the end: it alone refills
+                n0 = kChunkRecords - used;
+                pos0 = (unsigned long long)chunk * kChunkRecords + used;
+                const unsigned long long nc = atomicAdd(g_head, 1ull);
+                pos1 = nc * kChunkRecords;
+                __hip_atomic_store(&bl.alloc_state, (nc << 32) | (unsigned long long)(n - n0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 break;
             }
-            while ((uint32_t)(__hip_atomic_load(&bl.alloc_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == first)
+            while ((uint32_t)(__hip_atomic_load(&bl.alloc_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == chunk)
                 __builtin_amdgcn_s_sleep(2);
         }
     }
-    return __builtin_amdgcn_readfirstlane(unit);
-}
-
-template <int MODE>
-DEVFN void flush_unit(WaveLds<MODE> &w, BlockLds &bl, uint32_t &rqlen, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
-    rqlen -= kUnit;
-    wave_lds_fence();
-    const uint4 r = w.rq[rqlen + lane];
-    wave_lds_fence();
-    const uint32_t unit = alloc_unit(bl, &result[2], lane);
-    uint4 *d = emit_slot(tg, (unsigned long long)unit * kUnit + lane, result);
-    if (d) *d = r;
+    Slots sl;
+    sl.pos0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(pos0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pos0);
+    sl.pos1 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(pos1 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pos1);
+    sl.n0 = __builtin_amdgcn_readfirstlane(n0);
+    return sl;
 }
 
 // Phase 2 on up to 64 survivors.  Returns the number of valid candidate pairs of the batch.  PROBES == false keeps the
@@ -99,8 +95,7 @@ DEVFN void flush_unit(WaveLds<MODE> &w, BlockLds &bl, uint32_t &rqlen, const Emi
 // hot kernel -- they cost it half its occupancy in registers: such pairs go to a list that k_pairs_deferred finishes.
 template <int MODE, bool PROBES>
 DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
-                             unsigned long long base, uint32_t emitted, uint32_t &rqlen, const EmitTarget &tg, unsigned long long *result,
-                             uint32_t lane) {
+                             unsigned long long base, uint32_t emitted, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
     bool valid = false, swap = false;
     double s = 0.0;
     Fat a, b;
@@ -139,50 +134,29 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
                     vm = __ballot(valid);
                 }
             }
-            if (valid) w.rq[rqlen + mbcnt(vm)] = r;
-            rqlen += (uint32_t)__popcll(vm);
-            if (rqlen >= kUnit) flush_unit<MODE>(w, bl, rqlen, tg, result, lane);
+            const uint32_t n = (uint32_t)__popcll(vm);
+            if (n) {  // compacted, coalesced store of the batch's records straight from registers
+                const Slots sl = alloc_records(bl, &result[2], n, lane);
+                const uint32_t rank = mbcnt(vm);
+                if (valid) {
+                    uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
+                    if (d) *d = r;
+                }
+            }
         }
     }
     return nvalid;
 }
 
-// Block epilogue of the emit mode: merge the < 64 leftover records of the four waves so that the block leaves exactly ONE
-// hole (the unused tail of its last chunk) behind.  Every wave of the block must call it.
-template <typename WL>
-DEVFN void emit_epilogue(WL *wl, BlockLds &bl, uint32_t rqlen, const EmitTarget &tg, ulonglong2 *hole, unsigned long long *result,
-                         uint32_t wave, uint32_t lane) {
-    if (lane == 0) bl.left[wave] = rqlen;
+// Block epilogue of the emit mode: the unused tail of the block's last chunk is its (one) hole.  Every wave must call it.
+DEVFN void emit_epilogue(BlockLds &bl, ulonglong2 *hole) {
     __syncthreads();
-    uint32_t offs[kWavesPerBlock + 1];
-    offs[0] = 0;
-    for (int v = 0; v < kWavesPerBlock; v++) offs[v + 1] = offs[v] + bl.left[v];
-    const uint32_t total = offs[kWavesPerBlock], units = (total + kUnit - 1) / kUnit;
-    auto write_unit = [&](uint32_t uidx) -> uint32_t {
-        const uint32_t unit = alloc_unit(bl, &result[2], lane);
-        const uint32_t g = uidx * kUnit + lane;
-        if (g < total) {
-            const uint32_t sw = (g >= offs[1]) + (g >= offs[2]) + (g >= offs[3]);
-            uint4 *d = emit_slot(tg, (unsigned long long)unit * kUnit + lane, result);
-            if (d) *d = wl[sw].rq[g - offs[sw]];
-        }
-        return unit;
-    };
-    if (units > 1 && wave < units - 1) write_unit(wave);  // full units first ...
-    __syncthreads();
-    if (wave == 0) {                                        // ... the partial one last, so the hole behind it is contiguous
+    if (threadIdx.x == 0) {
+        const unsigned long long st = bl.alloc_state;
+        const uint32_t chunk = (uint32_t)(st >> 32), used = (uint32_t)st;
         unsigned long long hs = 0, hl = 0;
-        if (units >= 1) {
-            const uint32_t unit = write_unit(units - 1);
-            const unsigned long long st = bl.alloc_state;
-            hs = (unsigned long long)unit * kUnit + (total - (units - 1) * kUnit);
-            hl = ((st >> 32) + kUnitsPerChunk) * kUnit - hs;
-        } else {
-            const unsigned long long st = bl.alloc_state;
-            const uint32_t first = (uint32_t)(st >> 32), used = (uint32_t)st;
-            if (first != 0xFFFFFFFFu) { hs = ((unsigned long long)first + used) * kUnit; hl = (unsigned long long)(kUnitsPerChunk - used) * kUnit; }
-        }
-        if (lane == 0) *hole = make_ulonglong2(hs, hl);
+        if (chunk != 0xFFFFFFFFu && used < kChunkRecords) { hs = (unsigned long long)chunk * kChunkRecords + used; hl = kChunkRecords - used; }
+        *hole = make_ulonglong2(hs, hl);
     }
 }
 
@@ -199,7 +173,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
         for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
         if (threadIdx.x == 0) {
             prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
-            bl.alloc_state = (0xFFFFFFFFull << 32) | kUnitsPerChunk;  // "exhausted": the first allocation fetches a chunk
+            bl.alloc_state = (0xFFFFFFFFull << 32) | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
         }
         __syncthreads();
     }
@@ -213,7 +187,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
     const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
     uint32_t *ctr = task_ctr + MODE * 8 + group;
-    uint32_t rqlen = 0;  // emit mode: records waiting in w.rq (wave-uniform)
     uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); emit mode carries them across tasks
 #pragma unroll 1
     for (;;) {
@@ -276,14 +249,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
                     const uint32_t wbase = it0 < len ? off + it0 : 0u;
                     const float4 *win = w.nrec + wbase;
                     uint32_t mask = 0;
-                    // eight LDS reads in flight, then their eight tests: issued one by one, every test would pay the full LDS latency
+                    // kReadAhead LDS reads in flight, then their tests: issued one by one, every test would pay the full LDS latency
 #pragma unroll
-                    for (uint32_t u0 = 0; u0 < kBlock; u0 += 8) {
-                        float rx[8], ry[8], rz[8];
+                    for (uint32_t u0 = 0; u0 < kBlock; u0 += kReadAhead) {
+                        float rx[kReadAhead], ry[kReadAhead], rz[kReadAhead];
 #pragma unroll
-                        for (uint32_t u = 0; u < 8; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; }
+                        for (uint32_t u = 0; u < kReadAhead; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; }
 #pragma unroll
-                        for (uint32_t u = 0; u < 8; ++u) {
+                        for (uint32_t u = 0; u < kReadAhead; ++u) {
                             const float dx = rx[u] - home.x, dy = ry[u] - home.y, dz = rz[u] - home.z;
                             push_pass(mask, __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz)), r2f);
                         }
@@ -305,7 +278,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
                             wave_lds_fence();  // lanes read entries other lanes wrote
                             const uint2 ent = w.queue[qlen + lane];
                             wave_lds_fence();
-                            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, true, base, emitted, rqlen, tg, result, lane);
+                            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, true, base, emitted, tg, result, lane);
                         }
                     }
                 }
@@ -317,7 +290,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
             wave_lds_fence();
             const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
             wave_lds_fence();
-            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, base, emitted, rqlen, tg, result, lane);
+            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, base, emitted, tg, result, lane);
             qlen = 0;
         }
         if (MODE == kCountTasks && lane == 0) task_count[t] = emitted;
@@ -329,9 +302,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, cons
             wave_lds_fence();
             const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
             wave_lds_fence();
-            process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, 0ull, 0u, rqlen, tg, result, lane);
+            process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, 0ull, 0u, tg, result, lane);
         }
-        emit_epilogue(wl, bl, rqlen, tg, hole_list + blockIdx.x, result, wave, lane);
+        emit_epilogue(bl, hole_list + blockIdx.x);
     }
 }
 
@@ -349,28 +322,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
         for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
         if (threadIdx.x == 0) {
             prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
-            bl.alloc_state = (0xFFFFFFFFull << 32) | kUnitsPerChunk;
+            bl.alloc_state = (0xFFFFFFFFull << 32) | kChunkRecords;
         }
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long n = min(result[3], tg.defer_cap);
-    uint32_t rqlen = 0;
     for (unsigned long long e0 = ((unsigned long long)blockIdx.x * kWavesPerBlock + wave) * 64ull; e0 < n; e0 += (unsigned long long)gridDim.x * kWavesPerBlock * 64ull) {
         const bool act = e0 + lane < n;
         const uint2 ent = act ? tg.defer_list[e0 + lane] : make_uint2(0u, 0u);
-        process_batch<kEmit, true>(in, prm, so, wl[wave], bl, ent, act, 0ull, 0u, rqlen, tg, result, lane);
+        process_batch<kEmit, true>(in, prm, so, wl[wave], bl, ent, act, 0ull, 0u, tg, result, lane);
     }
-    emit_epilogue(wl, bl, rqlen, tg, hole_list + blockIdx.x, result, wave, lane);
+    emit_epilogue(bl, hole_list + blockIdx.x);
 }
 
 // Close the holes of the emit pass: with R = records reserved and P = R - sum(holes) valid ones, every hole slot below P
 // is filled with a valid record from [P, R).  No sorting is needed: a hole is the tail of ONE 2048-record chunk, so the
 // valid records above P are described by a per-chunk table over the <= n_holes + 1 chunks that [P, R) spans, and the
 // hole slots below P by the holes themselves in any order.  Each block rebuilds that (tiny) plan in LDS -- two
-// 1024-wide scans -- and then takes part in a grid-stride copy.
-constexpr uint32_t kFixThreads = 1024;       // >= number of holes + 1
-constexpr uint32_t kChunkRecords = kUnit * kUnitsPerChunk;
+// 2048-wide scans, two entries per thread -- and then takes part in a grid-stride copy.
+constexpr uint32_t kFixThreads = 1024;
+constexpr uint32_t kMaxHoles = 2 * kFixThreads;  // the launches keep emit blocks + deferred blocks < kMaxHoles
 DEVFN unsigned long long scan1024_u64(unsigned long long v, unsigned long long *red, unsigned long long *total) {
     const uint32_t i = threadIdx.x;
     unsigned long long inc = v;
@@ -388,36 +360,40 @@ DEVFN unsigned long long scan1024_u64(unsigned long long v, unsigned long long *
 }
 __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_list, uint32_t n_holes, const GridParams *g, EmitTarget tg,
                                                        unsigned long long *result) {
-    __shared__ unsigned long long fstart[kFixThreads], fpre[kFixThreads + 1];   // hole parts below P, any order
-    __shared__ unsigned long long tstart[kFixThreads], tpre[kFixThreads + 1];   // valid stretch of each chunk of [P, R)
-    __shared__ unsigned int tlen[kFixThreads];
+    __shared__ unsigned long long fstart[kMaxHoles], fpre[kMaxHoles + 1];  // hole parts below P, any order
+    __shared__ unsigned long long tpre[kMaxHoles + 1];                     // valid stretch of each chunk of [P, R) ...
+    __shared__ unsigned int tlen[kMaxHoles];                               // ... and its length
     __shared__ unsigned long long red[kFixThreads / 64];
-    const uint32_t i = threadIdx.x;
-    const ulonglong2 h = (i < n_holes) ? hole_list[i] : make_ulonglong2(0ull, 0ull);
-    const unsigned long long R = result[2] * kUnit;
+    const uint32_t i = threadIdx.x, e0 = 2u * i, e1 = e0 + 1u;
+    const ulonglong2 h0 = (e0 < n_holes) ? hole_list[e0] : make_ulonglong2(0ull, 0ull);
+    const ulonglong2 h1 = (e1 < n_holes) ? hole_list[e1] : make_ulonglong2(0ull, 0ull);
+    const unsigned long long R = result[2] * kChunkRecords;
     unsigned long long holes_total;
-    scan1024_u64(h.y, red, &holes_total);
+    scan1024_u64(h0.y + h1.y, red, &holes_total);
     const unsigned long long P = R - holes_total;
-    // tail chunks: chunk c0 + i, valid part = [max(chunk base, P), chunk end) minus the chunk's hole (set below)
-    const unsigned long long c0 = P / kChunkRecords, n_tail = R / kChunkRecords - c0;  // R is a multiple of the chunk size; n_tail <= n_holes + 1
-    {
-        const unsigned long long cb = (c0 + i) * kChunkRecords;
-        const unsigned long long ts = cb > P ? cb : P;
-        tstart[i] = ts;
-        tlen[i] = (i < n_tail) ? (unsigned int)(cb + kChunkRecords - ts) : 0u;
-    }
+    // tail chunks: chunk c0 + e, valid part = [max(chunk base, P), chunk end) minus the chunk's hole (set below)
+    const unsigned long long c0 = P / kChunkRecords, n_tail = R / kChunkRecords - c0;  // n_tail <= n_holes + 1 <= kMaxHoles
+    auto tail_start = [&](unsigned long long e) { const unsigned long long cb = (c0 + e) * kChunkRecords; return cb > P ? cb : P; };
+    tlen[e0] = (e0 < n_tail) ? (unsigned int)((c0 + e0 + 1) * kChunkRecords - tail_start(e0)) : 0u;
+    tlen[e1] = (e1 < n_tail) ? (unsigned int)((c0 + e1 + 1) * kChunkRecords - tail_start(e1)) : 0u;
     __syncthreads();
-    if (h.y && h.x / kChunkRecords >= c0) {  // this hole cuts the end off one tail chunk
-        const uint32_t j = (uint32_t)(h.x / kChunkRecords - c0);
-        tlen[j] = h.x > tstart[j] ? (unsigned int)(h.x - tstart[j]) : 0u;
-    }
+    auto cut = [&](const ulonglong2 &h) {  // a hole cuts the end off one tail chunk
+        if (h.y && h.x / kChunkRecords >= c0) {
+            const unsigned long long j = h.x / kChunkRecords - c0, ts = tail_start(j);
+            tlen[j] = h.x > ts ? (unsigned int)(h.x - ts) : 0u;
+        }
+    };
+    cut(h0); cut(h1);
     __syncthreads();
-    const unsigned long long f_len = (h.y && h.x < P) ? ((h.x + h.y < P ? h.x + h.y : P) - h.x) : 0ull;
+    auto front = [&](const ulonglong2 &h) { return (h.y && h.x < P) ? ((h.x + h.y < P ? h.x + h.y : P) - h.x) : 0ull; };
+    const unsigned long long f0 = front(h0), f1 = front(h1), t0 = tlen[e0], t1 = tlen[e1];
     unsigned long long F, T;
-    const unsigned long long fe = scan1024_u64(f_len, red, &F);
-    const unsigned long long te = scan1024_u64((unsigned long long)tlen[i], red, &T);
-    fstart[i] = h.x; fpre[i] = fe; tpre[i] = te;
-    if (i == 0) { fpre[kFixThreads] = F; tpre[kFixThreads] = T; }
+    const unsigned long long fe = scan1024_u64(f0 + f1, red, &F);
+    const unsigned long long te = scan1024_u64(t0 + t1, red, &T);
+    fstart[e0] = h0.x; fstart[e1] = h1.x;
+    fpre[e0] = fe; fpre[e1] = fe + f0;
+    tpre[e0] = te; tpre[e1] = te + t0;
+    if (i == 0) { fpre[kMaxHoles] = F; tpre[kMaxHoles] = T; }
     __syncthreads();
     if (blockIdx.x == 0 && i == 0) {
         result[0] = P;
@@ -427,12 +403,12 @@ __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_li
     }
     if (P > tg.capacity || F != T) return;  // the caller's buffer cannot hold the table: report the size only
     for (unsigned long long m = (unsigned long long)blockIdx.x * kFixThreads + i; m < F; m += (unsigned long long)gridDim.x * kFixThreads) {
-        uint32_t lo = 0, hi = kFixThreads;  // last k with fpre[k] <= m (zero-length entries are skipped by taking the last one)
+        uint32_t lo = 0, hi = kMaxHoles;  // last k with fpre[k] <= m (zero-length entries are skipped by taking the last one)
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (fpre[mid] <= m) lo = mid; else hi = mid; }
         const unsigned long long dst = fstart[lo] + (m - fpre[lo]);
-        uint32_t lo2 = 0, hi2 = kFixThreads;
+        uint32_t lo2 = 0, hi2 = kMaxHoles;
         while (hi2 - lo2 > 1) { const uint32_t mid = (lo2 + hi2) >> 1; if (tpre[mid] <= m) lo2 = mid; else hi2 = mid; }
-        const unsigned long long src = tstart[lo2] + (m - tpre[lo2]);
+        const unsigned long long src = tail_start(lo2) + (m - tpre[lo2]);
         uint4 *d = emit_slot(tg, dst, result);
         const uint4 *sp = emit_slot(tg, src, result);
         if (d && sp) *d = *sp;
@@ -469,7 +445,7 @@ static uint32_t blocks_for(uint32_t n, uint32_t cap) {
     return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
 
-unsigned long long emit_scratch_records() { return (unsigned long long)kFixThreads * (kUnitsPerChunk + 1) * kUnit; }
+unsigned long long emit_scratch_records() { return (unsigned long long)kMaxHoles * kChunkRecords; }
 
 void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered) {
     const uint32_t n = in.n;
@@ -527,10 +503,10 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
-    static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 880)
+    static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1900)
         const char *e = getenv("ARP_EMIT_BLOCKS");
         const long v = e ? atol(e) : 0;
-        return (v >= 8 && v <= (long)kEmitBlocks) ? (uint32_t)v : kEmitBlocks;
+        return (v >= 8 && v <= 1900) ? (uint32_t)v : kEmitBlocks;
     }();
     const uint32_t nb = blocks_for(in.n, emit_blocks);
     if (prof) prof->begin("pairs_emit", st);
