@@ -90,6 +90,11 @@ def _preload_hip_runtime():
 
 
 def _load():
+    import os
+
+    global LIB_PATH
+    if os.environ.get("ARPEGGIA_AMD_LIB"):  # diagnostic builds (timing ablations); same ABI
+        LIB_PATH = Path(os.environ["ARPEGGIA_AMD_LIB"])
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "

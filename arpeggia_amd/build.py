@@ -32,8 +32,9 @@ def needs_build() -> bool:
     return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = False, defines: tuple = (), out: Path | None = None) -> Path:
+    """defines/out: diagnostic builds only (e.g. -DARP_ABLATE=1 timing ablations, loaded through ARPEGGIA_AMD_LIB)."""
+    if not force and not defines and not needs_build():
         return LIB
     objs = []
     build_dir = PKG / "build"
@@ -41,19 +42,26 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     for src in SOURCES:
         obj = build_dir / (src.replace(".", "_") + ".o")
-        cmd = [cc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [cc, *FLAGS, *[f"-D{d}" for d in defines], "-c", str(CSRC / src), "-o", str(obj)]
         if src.endswith(".cpp"):
             cmd[1:1] = ["-x", "hip"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(str(obj))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB), "-lpthread"]
+    target = Path(out) if out else LIB
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(target), "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--define", action="append", default=[])
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    print(build_library(force=True, verbose=not a.define, defines=tuple(a.define), out=a.out))

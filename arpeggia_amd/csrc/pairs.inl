@@ -21,13 +21,14 @@
 //                 block) are closed afterwards by k_fixup, which moves the tail of the array into them.
 enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2 };
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 8;
 constexpr int kQueue = 128;
 constexpr uint32_t kChunk = 256;            // neighbour records per staged chunk (4 KB)
 constexpr uint32_t kBlock = 16;             // prefilter tests per lane between two compaction steps
 constexpr uint32_t kReadAhead = 4;         // LDS reads in flight per lane in the prefilter (more costs a wave of occupancy in registers)
 constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
-constexpr uint32_t kEmitBlocks = 1280;      // emit mode: 5 blocks per CU; with the 128 deferred blocks < 2048 holes (k_fixup's capacity)
+constexpr uint32_t kEmitBlocks = 768;       // emit mode: 3 blocks of 8 waves per CU (6 waves per SIMD)
+constexpr int kEmitWavesPerSimd = 6;         // register budget of the emit kernel: 80 VGPRs
 constexpr uint32_t kGrab = 2;              // wave-tasks drawn per atomic
 constexpr uint32_t kChunkRecords = 2048;    // records per global allocation (one device atomic each)
 
@@ -96,6 +97,9 @@ DEVFN Slots alloc_records(BlockLds &bl, unsigned long long *g_head, uint32_t n, 
 template <int MODE, bool PROBES>
 DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
                              unsigned long long base, uint32_t emitted, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
+#if defined(ARP_ABLATE) && ARP_ABLATE == 1   // timing ablation: no exact phase at all (results are wrong by construction)
+    return (uint32_t)__popcll(__ballot(active));
+#endif
     bool valid = false, swap = false;
     double s = 0.0;
     Fat a, b;
@@ -108,6 +112,9 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
     }
     unsigned long long vm = __ballot(valid);
     const uint32_t nvalid = (uint32_t)__popcll(vm);
+#if defined(ARP_ABLATE) && ARP_ABLATE == 2   // timing ablation: loads + exact test + orientation, nothing after
+    if (MODE == kEmit) { if (valid && s == 12345.678) atomicOr(&result[1], 32ull); return nvalid; }
+#endif
     if (MODE != kCountTasks) {
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (valid) {
@@ -161,7 +168,7 @@ DEVFN void emit_epilogue(BlockLds &bl, ulonglong2 *hole) {
 }
 
 template <int MODE, bool PROBES>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
+__global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? kEmitWavesPerSimd : 1) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
                                                                Sorted so, uint32_t *task_count, const unsigned long long *task_base,
                                                                EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     __shared__ LdsParams prm;

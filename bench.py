@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-atoms", type=int, default=400_000)
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--no-check", action="store_true", help="diagnostic (ablation) builds: do not assert the pair count")
     ap.add_argument("--deterministic", action="store_true", help="two-pass ordered emitter (ARP_FLAG_DETERMINISTIC)")
     return ap.parse_args()
 
@@ -118,7 +119,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    assert ctx.result() == n_pairs
+    got = ctx.result()
+    assert args.no_check or got == n_pairs
 
     def barrier():
         if dist is not None:
@@ -134,7 +136,8 @@ def main():
     ev1.record(stream)
     barrier()
     wall = time.perf_counter() - t0
-    assert ctx.result() == n_pairs
+    got = ctx.result()
+    assert args.no_check or got == n_pairs
     dev_ms = ev0.elapsed_time(ev1)
 
     # ---- per-kernel durations (HIP events on the same stream, separate pass so they do not perturb the timed region) ----
