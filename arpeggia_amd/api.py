@@ -298,6 +298,25 @@ class Context:
             lib.arp_table_free(t)
 
 
+def atomic_contacts_batch(contexts, atoms_list, params: _lib.arp_params | None = None) -> list:
+    """Independent structures over one or more device contexts (arp_contacts_atomic_batch): longest-first deal over the
+    contexts, small structures packed into shared launches.  Returns one pair array per structure, in input order."""
+    contexts = list(contexts)
+    keep = []
+    views = [atoms_from_arrays(a, keep=keep) if isinstance(a, dict) else a for a in atoms_list]
+    params = params or default_params()
+    arr = (C.POINTER(_lib.arp_atoms) * max(len(views), 1))(*[C.pointer(v) for v in views])
+    outs = (_lib.arp_pairs * max(len(views), 1))()
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    st = lib.arp_contacts_atomic_batch(handles, len(contexts), arr, len(views), C.byref(params), outs)
+    try:
+        _check(st)
+        return [_np_from(outs[k].data, int(outs[k].n), PAIR_DTYPE) for k in range(len(views))]
+    finally:
+        for k in range(len(views)):
+            lib.arp_pairs_free(C.byref(outs[k]))
+
+
 _default_ctx: dict = {}
 
 

@@ -384,10 +384,128 @@ extern "C" void arp_pairs_free(arp_pairs *pairs) {
     pairs->data = nullptr; pairs->n = 0;
 }
 
-// Independent structures, one host thread + one context (stream) per device, longest-processing-time-first deal.
+// ---- batches of independent structures ---------------------------------------------------------------------------
+// Small structures do not fill the chip (a 5k-atom structure is ~80 wave tasks for 256 CUs and the per-launch fixed
+// costs dominate), so a device's share of the batch is PACKED: consecutive structures are concatenated into one SoA
+// with their models renumbered to be distinct.  The reference never pairs atoms of different models
+// (complex.rs:96-98, 201-207), every model owns its own z slab of the grid, and no coordinate is touched, so the
+// pairs of a pack are exactly the union of the members' pairs; they are split back by the structure of `i`.
+namespace {
+constexpr uint64_t kPackAtoms = 4u << 20;   // atoms per pack: ~1 GiB of pairs at 16 pairs/atom
+constexpr uint32_t kPackModels = 60000;     // model ids are u16
+
+struct Pack {
+    std::vector<int32_t> members;
+    uint64_t n = 0, n_res = 0, n_h = 0;
+    uint32_t n_models = 0;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+};
+
+struct Extent {
+    double lo[3], hi[3];
+    uint32_t n_models;
+    bool packable;
+};
+
+Extent measure(const arp_atoms *a) {
+    Extent e{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}, 1, false};
+    if (!a || a->location != ARP_MEM_HOST || a->n == 0 || a->n_res == 0 || a->n >= kPackAtoms) return e;
+    if (!a->x || !a->y || !a->z || !a->attr || !a->res_ord || !a->chain_rank || !a->model || !a->res_id || !a->res_h_ptr || !a->res_cb || !a->res_sg)
+        return e;
+    if (a->res_h_ptr[a->n_res] && !a->res_h_idx) return e;
+    uint32_t mm = 0;
+    for (uint64_t i = 0; i < a->n; i++) {
+        const double p[3] = {a->x[i], a->y[i], a->z[i]};
+        for (int k = 0; k < 3; k++) {
+            if (!std::isfinite(p[k])) return e;  // the single-structure path reports it
+            e.lo[k] = std::min(e.lo[k], p[k]);
+            e.hi[k] = std::max(e.hi[k], p[k]);
+        }
+        mm = std::max<uint32_t>(mm, a->model[i]);
+    }
+    e.n_models = mm + 1;
+    e.packable = true;
+    return e;
+}
+
+// cells the shared grid would need (grid.inl grid_setup) against what the workspace gives a pack of n atoms
+bool grid_fits(const double lo[3], const double hi[3], uint32_t n_models, uint64_t n, double cutoff) {
+    const double edge = std::max(cutoff * (1.0 + 1e-6), 1e-3);
+    double cells = (double)n_models;
+    for (int k = 0; k < 3; k++) cells *= std::floor((hi[k] - lo[k]) / edge) + 1.0 + (k == 2 ? 1.0 : 0.0);
+    return cells <= 8.0 * (double)n;
+}
+
+arp_status run_pack(arp_context *ctx, const Pack &pk, const arp_atoms *const *atoms, const arp_params *params, arp_pairs *outs) {
+    const size_t K = pk.members.size();
+    std::vector<double> x(pk.n), y(pk.n), z(pk.n);
+    std::vector<uint32_t> attr(pk.n), res_ord(pk.n), res_id(pk.n), res_h_ptr(pk.n_res + 1), res_h_idx(pk.n_h), res_cb(pk.n_res), res_sg(pk.n_res);
+    std::vector<uint16_t> chain_rank(pk.n), model(pk.n);
+    std::vector<uint64_t> first(K + 1, 0);
+    uint64_t o = 0, ro = 0, ho = 0;
+    uint32_t mo = 0;
+    for (size_t m = 0; m < K; m++) {
+        const arp_atoms &a = *atoms[pk.members[m]];
+        first[m] = o;
+        memcpy(&x[o], a.x, a.n * 8); memcpy(&y[o], a.y, a.n * 8); memcpy(&z[o], a.z, a.n * 8);
+        memcpy(&attr[o], a.attr, a.n * 4); memcpy(&res_ord[o], a.res_ord, a.n * 4); memcpy(&chain_rank[o], a.chain_rank, a.n * 2);
+        uint32_t mm = 0;
+        for (uint64_t i = 0; i < a.n; i++) {
+            mm = std::max<uint32_t>(mm, a.model[i]);
+            model[o + i] = (uint16_t)(mo + a.model[i]);
+            res_id[o + i] = (uint32_t)(ro + a.res_id[i]);
+        }
+        const uint64_t nh = a.res_h_ptr[a.n_res];
+        for (uint64_t r = 0; r < a.n_res; r++) {
+            res_h_ptr[ro + r] = (uint32_t)(ho + a.res_h_ptr[r]);
+            res_cb[ro + r] = a.res_cb[r] == ARP_NONE ? ARP_NONE : (uint32_t)(o + a.res_cb[r]);
+            res_sg[ro + r] = a.res_sg[r] == ARP_NONE ? ARP_NONE : (uint32_t)(o + a.res_sg[r]);
+        }
+        for (uint64_t h = 0; h < nh; h++) res_h_idx[ho + h] = (uint32_t)(o + a.res_h_idx[h]);
+        o += a.n; ro += a.n_res; ho += nh; mo += mm + 1;
+    }
+    first[K] = o;
+    res_h_ptr[ro] = (uint32_t)ho;
+    arp_atoms all{};
+    all.n = o; all.x = x.data(); all.y = y.data(); all.z = z.data(); all.attr = attr.data(); all.res_ord = res_ord.data();
+    all.chain_rank = chain_rank.data(); all.model = model.data(); all.res_id = res_id.data(); all.n_res = ro;
+    all.res_h_ptr = res_h_ptr.data(); all.res_h_idx = res_h_idx.data(); all.res_cb = res_cb.data(); all.res_sg = res_sg.data();
+    all.location = ARP_MEM_HOST;
+    arp_pairs joint{};
+    arp_status s = arp_contacts_atomic(ctx, &all, params, ARP_MEM_HOST, &joint);
+    if (s != ARP_OK) return s;
+    // split by the structure of i, keeping the emitted order inside every structure
+    std::vector<uint32_t> owner(o);
+    for (size_t m = 0; m < K; m++) std::fill(owner.begin() + first[m], owner.begin() + first[m + 1], (uint32_t)m);
+    std::vector<uint64_t> count(K, 0);
+    for (uint64_t p = 0; p < joint.n; p++) count[owner[joint.data[p].i]]++;
+    for (size_t m = 0; m < K; m++) {
+        arp_pairs &out = outs[pk.members[m]];
+        out.n = count[m]; out.location = ARP_MEM_HOST; out.data = nullptr;
+        if (count[m] && !(out.data = (arp_pair *)malloc(count[m] * sizeof(arp_pair)))) {
+            for (size_t q = 0; q < m; q++) arp_pairs_free(&outs[pk.members[q]]);
+            arp_pairs_free(&joint);
+            set_error("out of host memory");
+            return ARP_ERR_OOM;
+        }
+        count[m] = 0;
+    }
+    for (uint64_t p = 0; p < joint.n; p++) {
+        arp_pair q = joint.data[p];
+        const uint32_t m = owner[q.i];
+        q.i -= (uint32_t)first[m]; q.j -= (uint32_t)first[m];
+        outs[pk.members[m]].data[count[m]++] = q;
+    }
+    arp_pairs_free(&joint);
+    return ARP_OK;
+}
+}  // namespace
+
+// One host thread + one context (stream) per device, longest-processing-time-first deal, packed launches per device.
 extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms, int32_t n_structures,
                                                 const arp_params *params, arp_pairs *outs) {
     if (!ctxs || n_ctx <= 0 || !atoms || n_structures < 0 || !outs || !params) { set_error("bad batch arguments"); return ARP_ERR_BAD_INPUT; }
+    for (int32_t k = 0; k < n_structures; k++) outs[k] = arp_pairs{0, nullptr, ARP_MEM_HOST, 0};
     std::vector<int32_t> order(n_structures);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return atoms[a]->n > atoms[b]->n; });
@@ -403,10 +521,42 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
     std::vector<std::thread> th;
     for (int d = 0; d < n_ctx; d++)
         th.emplace_back([&, d]() {
+            auto fail = [&](arp_status s) { st[d] = s; msg[d] = arp_last_error(); };
+            auto run_single = [&](int32_t k) { return arp_contacts_atomic(ctxs[d], atoms[k], params, ARP_MEM_HOST, &outs[k]); };
+            auto flush = [&](Pack &pk) {
+                arp_status s = ARP_OK;
+                if (pk.members.size() == 1) s = run_single(pk.members[0]);
+                else if (pk.members.size() > 1 && (s = run_pack(ctxs[d], pk, atoms, params, outs)) != ARP_OK && s != ARP_ERR_OOM && s != ARP_ERR_HIP) {
+                    // an input error inside the pack: rerun the members one by one so that the failing structure reports it
+                    s = ARP_OK;
+                    for (int32_t k : pk.members)
+                        if ((s = run_single(k)) != ARP_OK) break;
+                }
+                pk = Pack{};
+                return s;
+            };
+            Pack pk;
             for (int32_t k : queue[d]) {
-                arp_status s = arp_contacts_atomic(ctxs[d], atoms[k], params, ARP_MEM_HOST, &outs[k]);
-                if (s != ARP_OK) { st[d] = s; msg[d] = arp_last_error(); return; }
+                const Extent e = measure(atoms[k]);
+                arp_status s = ARP_OK;
+                if (!e.packable) {
+                    if ((s = flush(pk)) != ARP_OK || (s = run_single(k)) != ARP_OK) return fail(s);
+                    continue;
+                }
+                const arp_atoms &a = *atoms[k];
+                double lo[3], hi[3];
+                for (int c = 0; c < 3; c++) { lo[c] = std::min(pk.lo[c], e.lo[c]); hi[c] = std::max(pk.hi[c], e.hi[c]); }
+                if (!pk.members.empty() && (pk.n + a.n > kPackAtoms || pk.n_models + e.n_models > kPackModels ||
+                                            !grid_fits(lo, hi, pk.n_models + e.n_models, pk.n + a.n, params->dist_cutoff))) {
+                    if ((s = flush(pk)) != ARP_OK) return fail(s);
+                    for (int c = 0; c < 3; c++) { lo[c] = e.lo[c]; hi[c] = e.hi[c]; }
+                }
+                pk.members.push_back(k);
+                pk.n += a.n; pk.n_res += a.n_res; pk.n_h += a.res_h_ptr[a.n_res]; pk.n_models += e.n_models;
+                for (int c = 0; c < 3; c++) { pk.lo[c] = lo[c]; pk.hi[c] = hi[c]; }
             }
+            arp_status s = flush(pk);
+            if (s != ARP_OK) fail(s);
         });
     for (auto &t : th) t.join();
     for (int d = 0; d < n_ctx; d++)

@@ -162,6 +162,8 @@ def main():
                 traffic = {"hbm_bytes_per_launch": tr["hbm_bytes_per_launch"], "kernel": tr["kernel"], "source": tr["source"]}
         except (OSError, KeyError, ValueError):
             pass
+        if not acc:  # --profile-steps 0 (external profiler runs): fall back to the whole device-side step
+            acc = {"pipeline": dev_ms / args.steps}
         dom = max(acc, key=acc.get)
         alg_bytes = 36.0 * n + 16.0 * n_pairs  # 36 B/atom read once + 16 B per classified pair written
         dom_ms = acc[dom]

@@ -306,6 +306,47 @@ def test_batch_of_structures(ctx):
         assert np.array_equal(canon(got), canon(singles[k]))
 
 
+def test_packed_batch_equals_single_calls(ctx):
+    """Packing renumbers models and offsets residue tables; the split result must equal every single call, and the
+    single calls are oracle-checked (6bft, 1ubq, stress clouds with hydrogens, a two-model NMR-like structure)."""
+    structs = [aa.load_model(str(synth.DATA / "1ubq.pdb")), aa.load_model(str(synth.DATA / "6bft.pdb"))]
+    structs += [aa.Structure.from_records(synth.gen_stress(n_res=120 + 40 * k, seed=60 + k)) for k in range(4)]
+    two = synth.gen_stress(n_res=90, seed=77, n_models=2)
+    structs.append(aa.Structure.from_records(two))
+    far = synth.gen_stress(n_res=80, seed=78)
+    far["x"] += 5.0e4  # a member that would blow up the shared grid starts its own pack
+    structs.append(aa.Structure.from_records(far))
+    empty = {k: v[:0] for k, v in two.items()}
+    structs.append(aa.Structure.from_records(empty))
+    views = [s.view("/") for s in structs]
+    singles = [ctx.atomic_contacts(v) for v in views]
+    assert len(singles[-1]) == 0 and len(singles[0]) == 9128
+    for prm in (aa.default_params(), aa.default_params(deterministic=True)):
+        got = aa.atomic_contacts_batch([ctx], views, prm)
+        assert len(got) == len(views)
+        for k in range(len(views)):
+            assert np.array_equal(canon(got[k]), canon(singles[k])), k
+    # the oracle on one packed member, to pin the whole chain
+    orc = ob.Structure.load(str(synth.DATA / "6bft.pdb"))
+    assert_pairs_equal(got[1], orc.atomic_contacts(), "6bft from a pack")
+
+
+def test_packed_batch_reports_the_failing_structure(ctx):
+    ok = synth.gen_stress(n_res=60, seed=21, hydrogens=False)
+    bad = {k: v[:4].copy() for k, v in ok.items()}
+    bad["name"][:] = [b"SG", b"CA", b"SG", b"CA"]
+    bad["resn"][:] = b"CYS"
+    bad["element"][:] = [b"S", b"C", b"S", b"C"]
+    bad["chain"][:] = [b"Y", b"Y", b"Z", b"Z"]
+    bad["resi"][:] = [1, 1, 5, 5]
+    bad["x"][:] = [0.0, 1.5, 2.05, 3.5]; bad["y"][:] = 0.0; bad["z"][:] = 0.0
+    structs = [aa.Structure.from_records(r) for r in (ok, bad, ok)]
+    with pytest.raises(aa.ArpeggiaError) as e:
+        aa.atomic_contacts_batch([ctx], [s.view("/") for s in structs])
+    assert e.value.status == _lib.ARP_ERR_BAD_INPUT and "CB" in str(e.value)
+    assert len(aa.atomic_contacts_batch([ctx], [structs[0].view("/"), structs[2].view("/")])) == 2
+
+
 # ---------------------------------------------------------------------------------------------- the table (get_contacts)
 def _table_lines(cols):
     out = []
