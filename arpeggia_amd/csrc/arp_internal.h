@@ -21,7 +21,7 @@ struct DevParams {
     double s_vdw[256];    // lt(vdw[a]+vdw[b] + c)   vdw.rs:41
     double s_hacc[16];    // le(h_vdw + vdw[acceptor] + c)   hbond.rs:54,98
     float r2f;            // prefilter threshold in f32 (r2 + margin), set by the grid setup kernel
-    uint32_t pad;
+    uint32_t flags;       // arp_params.flags (ARP_FLAG_CONTACTS_ONLY is read by the pair kernels)
 };
 
 // Uniform grid, written by the device-side setup kernel (no host round trip).
@@ -101,7 +101,7 @@ struct Profiler {
 
 // Launch wrappers (kernels.hip / pairs.inl).  All asynchronous on `st`.
 void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered);
-void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out);
+void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out, bool contacts_only);
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 unsigned long long emit_scratch_records();

@@ -73,6 +73,7 @@ void make_dev_params(const arp_params &p, DevParams *d) {
         d->s_hacc[a] = bound_le(p.h_vdw_radius + p.vdw_radius[a] + c);  // hbond.rs:54
     }
     d->r2f = (float)d->r2;
+    d->flags = p.flags;
 }
 
 }  // namespace arp
@@ -301,12 +302,12 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
     if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
-    const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0;
+    const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
     launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered);
     if (!out || capacity == 0) {
-        launch_count(d, ctx->ws, ctx->stream, prof, 0, true);  // size query: reports ARP_ERR_CAPACITY + the count
+        launch_count(d, ctx->ws, ctx->stream, prof, 0, true, only);  // size query: reports ARP_ERR_CAPACITY + the count
     } else if (params->flags & ARP_FLAG_DETERMINISTIC) {
-        launch_count(d, ctx->ws, ctx->stream, prof, capacity, true);
+        launch_count(d, ctx->ws, ctx->stream, prof, capacity, true, only);
         launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof);
     } else {
         launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof);
@@ -346,14 +347,16 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
-    // count pass -> exact output size -> ordered fill or single-pass emit
-    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, (params->flags & ARP_FLAG_DETERMINISTIC) != 0);
-    launch_count(d, ctx->ws, ctx->stream, prof, 0, false);
+    // count pass -> output size -> ordered fill or single-pass emit.  With ARP_FLAG_CONTACTS_ONLY the single-pass emitter
+    // sizes the device buffer by the (cheap) candidate count, an upper bound; the ordered one needs the exact filtered counts.
+    const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered);
+    launch_count(d, ctx->ws, ctx->stream, prof, 0, false, only && ordered);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
-    const unsigned long long total = ctx->h_result[0];
+    unsigned long long total = ctx->h_result[0];
     if (total == 0) return ARP_OK;
     arp_pair *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
@@ -364,6 +367,8 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(dev); set_error("HIP error %d (%s) in the fill pass", (int)e, hipGetErrorString(e)); return ARP_ERR_HIP; }
     if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) { (void)hipFree(dev); return s; }
+    total = std::min<unsigned long long>(total, ctx->h_result[0]);  // fewer than the candidates with ARP_FLAG_CONTACTS_ONLY
+    if (total == 0) { (void)hipFree(dev); return ARP_OK; }
     if (out_location == ARP_MEM_DEVICE) {
         out->data = dev; out->n = total;
         return ARP_OK;

@@ -50,6 +50,7 @@ DEVFN void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefron
 struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB)
     double s_clash[256], s_cov[256], s_vdw[256], s_hacc[16];
     double r2, s_ion, s_polar, s_hphob;
+    uint32_t contacts_only;
 };
 
 // should_compare_entities(x, y, symmetric = true) for x in L, y in R (complex.rs:76-131, 200-206), evaluated for both

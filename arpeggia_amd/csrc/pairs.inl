@@ -19,7 +19,8 @@
 //                 coalesced stores) into chunks that a block-level LDS bump allocator carves out of ONE global
 //                 counter (one device atomic per 2048 records).  The few unused chunk tails ("holes", one per
 //                 block) are closed afterwards by k_fixup, which moves the tail of the array into them.
-enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2 };
+enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2, kCountContacts = 3 };
+//   kCountContacts  kCountTasks for ARP_FLAG_CONTACTS_ONLY: classifies, counts only the pairs with an interaction
 
 constexpr int kWavesPerBlock = 8;
 constexpr int kQueue = 128;
@@ -122,6 +123,11 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
             r.z = __float_as_uint(dist_f32(s));
         }
+        if (prm.contacts_only) {  // ARP_FLAG_CONTACTS_ONLY: candidates without any interaction are dropped (kDeferKind != 0 stays)
+            valid = valid && r.w != 0u;
+            vm = __ballot(valid);
+        }
+        if (MODE == kCountContacts) return (uint32_t)__popcll(vm);
         if (MODE == kFillOrdered) {
             const unsigned long long pos = base + emitted + mbcnt(vm);
             if (valid && pos < tg.capacity) reinterpret_cast<uint4 *>(tg.out)[pos] = r;
@@ -151,6 +157,7 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
                 }
             }
         }
+        return (uint32_t)__popcll(vm);
     }
     return nvalid;
 }
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
         for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
         if (threadIdx.x == 0) {
             prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
+            prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
             bl.alloc_state = (0xFFFFFFFFull << 32) | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
         }
         __syncthreads();
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
             emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, base, emitted, tg, result, lane);
             qlen = 0;
         }
-        if (MODE == kCountTasks && lane == 0) task_count[t] = emitted;
+        if ((MODE == kCountTasks || MODE == kCountContacts) && lane == 0) task_count[t] = emitted;
     }
     }
     if (MODE == kEmit) {
@@ -329,6 +337,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
         for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
         if (threadIdx.x == 0) {
             prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
+            prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
             bl.alloc_state = (0xFFFFFFFFull << 32) | kChunkRecords;
         }
         __syncthreads();
@@ -486,10 +495,11 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
 }
 
 // candidate pairs per task + their scan + total (result[0])
-void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out) {
+void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out, bool contacts_only) {
     EmitTarget none{nullptr, 0ull, nullptr, 0ull, nullptr, 0ull};
     if (prof) prof->begin("pairs_count", st);
-    hipLaunchKernelGGL((k_pairs<kCountTasks, true>), dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+    auto kern = contacts_only ? k_pairs<kCountContacts, true> : k_pairs<kCountTasks, true>;
+    hipLaunchKernelGGL(kern, dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
                        (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
                        (const unsigned long long *)ws.task_base, none, ws.hole_list, ws.task_ctr, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_scan", st); }

@@ -212,6 +212,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     arp_params prm;
     arp_default_params(&prm);
     prm.vdw_comp = vdw_comp; prm.dist_cutoff = dist_cutoff;
+    prm.flags |= ARP_FLAG_CONTACTS_ONLY;  // only pairs with an interaction become rows: filter them before the copy to the host
     arp_pairs pairs{};
     st = arp_contacts_atomic(ctx, &view, &prm, ARP_MEM_HOST, &pairs);
     if (st != ARP_OK) return st;

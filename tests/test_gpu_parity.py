@@ -331,6 +331,45 @@ def test_packed_batch_equals_single_calls(ctx):
     assert_pairs_equal(got[1], orc.atomic_contacts(), "6bft from a pack")
 
 
+@pytest.mark.parametrize("source", ["6bft", "stress", "s1"])
+def test_contacts_only_is_the_kind_filter_of_the_full_list(ctx, source):
+    """ARP_FLAG_CONTACTS_ONLY drops kind == 0 candidates on the device (the rows get_atomic_contacts never makes,
+    complex.rs:208-297); both emitters, the size query and the packed batch agree with filtering the oracle's list."""
+    if source == "6bft":
+        path = str(synth.DATA / "6bft.pdb")
+        prod, orc = aa.load_model(path), ob.Structure.load(path)
+    elif source == "stress":
+        rec = synth.gen_stress(n_res=400, seed=7)
+        prod = aa.Structure.from_records(rec)
+        orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+    else:
+        rec = synth.gen_s1(60000)
+        prod = aa.Structure.from_records(rec, hierarchy=True)
+        orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True)
+    want = orc.atomic_contacts()
+    want = want[want["kind"] != 0]
+    assert 0 < len(want)
+    view = prod.view("/")
+    for det in (False, True):
+        prm = aa.default_params(deterministic=det, contacts_only=True)
+        got = ctx.atomic_contacts(view, prm)
+        assert_pairs_equal(got, want, f"{source} contacts-only det={det}")
+    assert_pairs_equal(aa.atomic_contacts_batch([ctx], [view, view], aa.default_params(contacts_only=True))[1], want, "packed contacts-only")
+    torch = pytest.importorskip("torch")
+    soa = prod.soa("/")
+    dev = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda() for k, v in soa.items()}
+    keep = []
+    atoms = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
+    c2 = aa.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    for det in (False, True):
+        prm = aa.default_params(deterministic=det, contacts_only=True)
+        assert c2.count(atoms, prm) == len(want)
+        out = torch.empty((len(want), 4), dtype=torch.int32, device="cuda")
+        c2.enqueue(atoms, prm, out.data_ptr(), len(want))
+        assert c2.result() == len(want)
+        assert_pairs_equal(out.cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1), want, f"{source} resident contacts-only det={det}")
+
+
 def test_packed_batch_reports_the_failing_structure(ctx):
     ok = synth.gen_stress(n_res=60, seed=21, hydrogens=False)
     bad = {k: v[:4].copy() for k, v in ok.items()}
