@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
                 acc.mx[k] = use ? fmax(acc.mx[k], p[u][k]) : acc.mx[k];
             }
             acc.models = use ? max(acc.models, md[u] + 1u) : acc.models;
+            acc.bad |= use ? (0x100u << (at[u] & ARP_ATTR_ELEM_MASK)) : 0u;  // bits 8..23: element classes present in the grid
         }
     }
     box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
@@ -122,7 +123,23 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
         acc.models = max(acc.models, (uint32_t)p[6]); acc.bad |= (uint32_t)p[7];
     }
     box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
-    if (threadIdx.x == 0) grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad, g, prm, cutoff, ncells_cap);
+    // ARP_FLAG_CONTACTS_ONLY: no rule can match beyond the largest decision bound of the element pairs that are present
+    // (every rule of classify() is `s < bound`), so the search radius shrinks to it -- for C/N/O/S that is the 4.5 A of the
+    // hydrophobic rule -- and the dropped candidates are exactly ones the flag would have filtered out.
+    __shared__ double s_bound[4];
+    if (prm->flags & ARP_FLAG_CONTACTS_ONLY) {
+        const uint32_t present = acc.bad >> 8, ea = threadIdx.x >> 4, eb = threadIdx.x & 15u;
+        double b = fmax(prm->s_hphob, fmax(prm->s_ion, prm->s_polar));
+        if ((present >> ea) & (present >> eb) & 1u) b = fmax(b, fmax(prm->s_clash[threadIdx.x], fmax(prm->s_cov[threadIdx.x], prm->s_vdw[threadIdx.x])));
+        for (int off = 32; off; off >>= 1) b = fmax(b, __shfl_xor(b, off));
+        if ((threadIdx.x & 63) == 0) s_bound[threadIdx.x >> 6] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            b = fmax(fmax(s_bound[0], s_bound[1]), fmax(s_bound[2], s_bound[3]));
+            if (b < prm->r2) { prm->r2 = b; cutoff = sqrt(b); }
+        }
+    }
+    if (threadIdx.x == 0) grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap);
 }
 
 DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-check", action="store_true", help="diagnostic (ablation) builds: do not assert the pair count")
     ap.add_argument("--deterministic", action="store_true", help="two-pass ordered emitter (ARP_FLAG_DETERMINISTIC)")
+    ap.add_argument("--contacts-only", action="store_true",
+                    help="informational: ARP_FLAG_CONTACTS_ONLY (what the table path runs); `value` then counts emitted contacts, not the headline metric")
     return ap.parse_args()
 
 
@@ -106,7 +108,7 @@ def main():
     dsoa = to_device(soa, torch, dev)
     keep = []
     atoms = aa.atoms_from_arrays(dsoa, location=_lib.ARP_MEM_DEVICE, keep=keep)
-    prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic)
+    prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only)
     stream = torch.cuda.current_stream(dev)
     ctx = aa.Context(local_rank, stream=stream.cuda_stream)
 
@@ -158,7 +160,7 @@ def main():
         traffic = None
         try:
             tr = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
-            if tr["workload"] == args.workload and tr["atoms"] == n and not args.deterministic:
+            if tr["workload"] == args.workload and tr["atoms"] == n and not args.deterministic and not args.contacts_only:
                 traffic = {"hbm_bytes_per_launch": tr["hbm_bytes_per_launch"], "kernel": tr["kernel"], "source": tr["source"]}
         except (OSError, KeyError, ValueError):
             pass
@@ -179,7 +181,7 @@ def main():
             "config": {
                 "workload": f"{args.workload.upper()} synthetic {n}-atom cloud per GPU (tests/synth.py gen_{args.workload}), groups='/', vdw_comp=0.1, dist_cutoff=6.5",
                 "atoms_per_gpu": n, "pairs_per_gpu": n_pairs, "sharding": "one independent structure per rank, no collective",
-                "emitter": "ordered two-pass" if args.deterministic else "single-pass",
+                "emitter": ("ordered two-pass" if args.deterministic else "single-pass") + (", contacts only (kind != 0)" if args.contacts_only else ""),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
