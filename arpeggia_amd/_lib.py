@@ -90,6 +90,16 @@ def _preload_hip_runtime():
     return path
 
 
+class ArrowSchema(C.Structure):  # Arrow C Data Interface (ABI-stable), include/arpeggia_amd.h
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+                ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class ArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+                ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
 def _load():
     import os
 
@@ -134,6 +144,7 @@ def _load():
         "arp_table_free": (None, [vp]),
         "arp_table_rows": (C.c_uint64, [vp]),
         "arp_table_column": (vp, [vp, C.c_char_p, C.POINTER(C.c_int32)]),
+        "arp_table_export_arrow": (C.c_int32, [vp, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == the library does not export what the header declares

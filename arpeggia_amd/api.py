@@ -333,8 +333,26 @@ def load_model(input_file, ignore_zero_occupancy: bool = False) -> Structure:
 
 
 def get_contacts(structure: Structure, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5, device: int = 0):
-    """`arpeggia::get_contacts(&pdb, groups, vdw_comp, dist_cutoff) -> DataFrame` (mod.rs:61)."""
-    return _to_frame(_context(device).get_contacts(structure, groups, vdw_comp, dist_cutoff))
+    """`arpeggia::get_contacts(&pdb, groups, vdw_comp, dist_cutoff) -> DataFrame` (mod.rs:61).
+
+    The table crosses into Python as one Arrow record batch (arp_table_export_arrow): no per-row Python work."""
+    import pyarrow as pa
+
+    ctx = _context(device)
+    t = C.c_void_p()
+    _check(lib.arp_get_contacts(ctx._h, structure._h, groups.encode(), vdw_comp, dist_cutoff, C.byref(t)))
+    try:
+        arr, sch = _lib.ArrowArray(), _lib.ArrowSchema()
+        _check(lib.arp_table_export_arrow(t, C.byref(arr), C.byref(sch)))
+    finally:
+        lib.arp_table_free(t)
+    table = pa.Table.from_batches([pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))])
+    try:  # the reference returns a polars.DataFrame (python.rs:55); same Arrow buffers when polars is installed
+        import polars as pl
+
+        return pl.from_arrow(table)
+    except ImportError:
+        return table
 
 
 def _to_frame(cols: dict):

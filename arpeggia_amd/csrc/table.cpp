@@ -383,3 +383,146 @@ extern "C" const void *arp_table_column(const arp_table *t, const char *name, in
     if (c == "to_altloc") return num(t->to_altloc.buf.data(), 4);
     return nullptr;
 }
+
+// ---- Arrow C Data Interface export (mod.rs:140-214: the DataFrame the reference returns) ---------------------------------
+namespace {
+struct ArrowCol {  // owns the buffers of one child array
+    std::vector<uint8_t> validity;
+    std::vector<int32_t> offsets;
+    std::vector<char> bytes;
+    const void *bufs[3] = {nullptr, nullptr, nullptr};
+};
+struct ArrowBatch {  // private data of the struct array
+    std::vector<ArrowArray> kids;
+    std::vector<ArrowArray *> kid_ptrs;
+    const void *bufs[1] = {nullptr};
+};
+struct ArrowFields {  // private data of the struct schema
+    std::vector<ArrowSchema> kids;
+    std::vector<ArrowSchema *> kid_ptrs;
+};
+void release_col(ArrowArray *a) {
+    delete (ArrowCol *)a->private_data;
+    a->release = nullptr;
+}
+void release_batch(ArrowArray *a) {
+    ArrowBatch *b = (ArrowBatch *)a->private_data;
+    for (ArrowArray &k : b->kids)
+        if (k.release) k.release(&k);
+    delete b;
+    a->release = nullptr;
+}
+void release_leaf_schema(ArrowSchema *s) { s->release = nullptr; }
+void release_fields(ArrowSchema *s) {
+    ArrowFields *f = (ArrowFields *)s->private_data;
+    for (ArrowSchema &k : f->kids)
+        if (k.release) k.release(&k);
+    delete f;
+    s->release = nullptr;
+}
+template <typename T>
+ArrowCol *numeric_col(const std::vector<T> &v) {
+    ArrowCol *c = new ArrowCol();
+    c->bytes.resize(v.size() * sizeof(T) + 8);
+    memcpy(c->bytes.data(), v.data(), v.size() * sizeof(T));
+    c->bufs[1] = c->bytes.data();
+    return c;
+}
+template <int W>
+ArrowCol *utf8_col(const StrCol<W> &v) {
+    ArrowCol *c = new ArrowCol();
+    const size_t n = v.size();
+    c->offsets.resize(n + 1);
+    c->bytes.reserve(n * 3 + 8);
+    int32_t o = 0;
+    for (size_t i = 0; i < n; i++) {
+        c->offsets[i] = o;
+        const char *p = v.at(i);
+        int len = 0;
+        while (len < W && p[len]) len++;
+        c->bytes.insert(c->bytes.end(), p, p + len);
+        o += len;
+    }
+    c->offsets[n] = o;
+    c->bytes.resize(c->bytes.size() + 8);  // never hand out a null data pointer
+    c->bufs[1] = c->offsets.data(); c->bufs[2] = c->bytes.data();
+    return c;
+}
+}  // namespace
+
+extern "C" arp_status arp_table_export_arrow(const arp_table *t, ArrowArray *out_array, ArrowSchema *out_schema) {
+    if (!t || !out_array || !out_schema) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
+    if (t->n > 0x7FFFFFF0ull) { set_error("table too large for 32-bit utf8 offsets"); return ARP_ERR_BAD_INPUT; }
+    const int64_t n = (int64_t)t->n;
+    struct Field { const char *name, *format; ArrowCol *col; int64_t n_buffers; bool nullable; };
+    auto names_col = [&]() {  // interaction code -> the reference's Display string (structs.rs:6-51)
+        ArrowCol *c = new ArrowCol();
+        c->offsets.resize(n + 1);
+        int32_t o = 0;
+        for (int64_t i = 0; i < n; i++) {
+            c->offsets[i] = o;
+            const char *s = arp_interaction_name(t->interaction[i]);
+            const size_t len = strlen(s);
+            c->bytes.insert(c->bytes.end(), s, s + len);
+            o += (int32_t)len;
+        }
+        c->offsets[n] = o;
+        c->bytes.resize(c->bytes.size() + 8);
+        c->bufs[1] = c->offsets.data(); c->bufs[2] = c->bytes.data();
+        return c;
+    };
+    int64_t sc_nulls = 0;
+    auto sc_col = [&](const std::vector<float> &v) {  // null where either residue has no side-chain plane (mod.rs:100-110 left join)
+        ArrowCol *c = numeric_col(v);
+        c->validity.assign((size_t)(n + 7) / 8 + 8, 0);
+        sc_nulls = 0;
+        for (int64_t i = 0; i < n; i++) {
+            if (t->sc_valid[i]) c->validity[i >> 3] |= (uint8_t)(1u << (i & 7));
+            else sc_nulls++;
+        }
+        c->bufs[0] = c->validity.data();
+        return c;
+    };
+    std::vector<Field> fields = {
+        {"model", "I", numeric_col(t->model), 2, false}, {"interaction", "u", names_col(), 3, false}, {"distance", "f", numeric_col(t->distance), 2, false},
+        {"from_chain", "u", utf8_col(t->from_chain), 3, false}, {"from_resn", "u", utf8_col(t->from_resn), 3, false},
+        {"from_resi", "i", numeric_col(t->from_resi), 2, false}, {"from_insertion", "u", utf8_col(t->from_insertion), 3, false},
+        {"from_altloc", "u", utf8_col(t->from_altloc), 3, false}, {"from_atomn", "u", utf8_col(t->from_atomn), 3, false},
+        {"from_atomi", "i", numeric_col(t->from_atomi), 2, false},
+        {"to_chain", "u", utf8_col(t->to_chain), 3, false}, {"to_resn", "u", utf8_col(t->to_resn), 3, false},
+        {"to_resi", "i", numeric_col(t->to_resi), 2, false}, {"to_insertion", "u", utf8_col(t->to_insertion), 3, false},
+        {"to_altloc", "u", utf8_col(t->to_altloc), 3, false}, {"to_atomn", "u", utf8_col(t->to_atomn), 3, false},
+        {"to_atomi", "i", numeric_col(t->to_atomi), 2, false},
+        {"sc_centroid_dist", "f", sc_col(t->sc_dist), 2, true}, {"sc_dihedral", "f", sc_col(t->sc_dihedral), 2, true},
+        {"sc_centroid_angle", "f", sc_col(t->sc_angle), 2, true},
+    };
+    ArrowBatch *b = new ArrowBatch();
+    ArrowFields *f = new ArrowFields();
+    b->kids.resize(fields.size()); f->kids.resize(fields.size());
+    for (size_t k = 0; k < fields.size(); k++) {
+        ArrowArray &a = b->kids[k];
+        a = ArrowArray{};
+        a.length = n; a.null_count = fields[k].nullable ? sc_nulls : 0; a.offset = 0;
+        a.n_buffers = fields[k].n_buffers; a.n_children = 0;
+        a.buffers = fields[k].col->bufs; a.children = nullptr; a.dictionary = nullptr;
+        a.release = release_col; a.private_data = fields[k].col;
+        b->kid_ptrs.push_back(&a);
+        ArrowSchema &s = f->kids[k];
+        s = ArrowSchema{};
+        s.format = fields[k].format; s.name = fields[k].name; s.metadata = nullptr;
+        s.flags = fields[k].nullable ? 2 /* ARROW_FLAG_NULLABLE */ : 0;
+        s.n_children = 0; s.children = nullptr; s.dictionary = nullptr;
+        s.release = release_leaf_schema; s.private_data = nullptr;
+        f->kid_ptrs.push_back(&s);
+    }
+    *out_array = ArrowArray{};
+    out_array->length = n; out_array->null_count = 0; out_array->offset = 0;
+    out_array->n_buffers = 1; out_array->buffers = b->bufs;
+    out_array->n_children = (int64_t)fields.size(); out_array->children = b->kid_ptrs.data(); out_array->dictionary = nullptr;
+    out_array->release = release_batch; out_array->private_data = b;
+    *out_schema = ArrowSchema{};
+    out_schema->format = "+s"; out_schema->name = ""; out_schema->metadata = nullptr; out_schema->flags = 0;
+    out_schema->n_children = (int64_t)fields.size(); out_schema->children = f->kid_ptrs.data(); out_schema->dictionary = nullptr;
+    out_schema->release = release_fields; out_schema->private_data = f;
+    return ARP_OK;
+}

@@ -203,6 +203,29 @@ uint64_t arp_table_rows(const arp_table *t);
  * "from_atom"/"to_atom" i32 atom indices (-1 for a "Ring" entity). */
 const void *arp_table_column(const arp_table *t, const char *name, int32_t *width);
 
+/* The same 20 columns through the Arrow C Data Interface (a struct array = one record batch; utf8 strings, nullable
+ * f32 sc_* columns): what pyo3-polars hands to Python in the reference (python.rs:55, mod.rs:140-214), importable with
+ * zero per-row work by pyarrow / polars / arrow-rs (`FFI_ArrowArray`).  The exported arrays own copies of the columns:
+ * the table may be freed before they are released.  Struct layout per the Arrow specification (ABI-stable). */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char *format, *name, *metadata;
+    int64_t flags, n_children;
+    struct ArrowSchema **children, *dictionary;
+    void (*release)(struct ArrowSchema *);
+    void *private_data;
+};
+struct ArrowArray {
+    int64_t length, null_count, offset, n_buffers, n_children;
+    const void **buffers;
+    struct ArrowArray **children, *dictionary;
+    void (*release)(struct ArrowArray *);
+    void *private_data;
+};
+#endif
+arp_status arp_table_export_arrow(const arp_table *t, struct ArrowArray *out_array, struct ArrowSchema *out_schema);
+
 #ifdef __cplusplus
 }
 #endif

@@ -442,6 +442,31 @@ def test_contacts_drop_in_surface(ctx):
     assert (df2.height if hasattr(df2, "height") else df2.num_rows) == 532
 
 
+@pytest.mark.parametrize("name", ["1ubq", "6bft"])
+def test_arrow_export_equals_the_column_accessors(ctx, name):
+    """arp_table_export_arrow (what contacts() returns) against arp_table_column (what the golden comparison reads)."""
+    import pyarrow as pa
+
+    s = aa.load_model(str(synth.DATA / f"{name}.pdb"))
+    cols = ctx.get_contacts(s, "/", 0.1, 6.5)
+    df = aa.get_contacts(s)
+    tab = df if isinstance(df, pa.Table) else df.to_arrow()
+    assert tab.num_rows == len(cols["model"]) and tab.num_columns == 20
+    for cname, kind in aa.TABLE_COLUMNS:
+        got = tab.column(cname).to_pylist()
+        if cname == "interaction":
+            want = [_lib.INTERACTIONS[k] for k in cols[cname]]
+        elif kind == "str":
+            want = [v.decode() for v in cols[cname]]
+        elif cname.startswith("sc_"):
+            want = [float(v) if ok else None for v, ok in zip(cols[cname], cols["sc_valid"])]
+            assert tab.column(cname).null_count == int((~cols["sc_valid"]).sum())
+        else:
+            want = cols[cname].tolist()
+        assert got == want, cname
+    tab.validate(full=True)
+
+
 def test_table_on_stress_structure_matches_oracle_table(ctx, tmp_path):
     rec = synth.gen_stress(n_res=250, seed=31, n_chains=3)
     p = tmp_path / "stress.pdb"
