@@ -61,6 +61,11 @@ struct Sorted {
     uint2 *hinfo;         // [begin, end) of the residue's hydrogens in res_h_idx
 };
 
+// Same-address (and same-line) device atomics serialise in one L2 channel at ~90 ns each: the task counters of the eight XCD
+// groups sit in separate 128-byte lines (measured: sharing one line cost the emit kernel 155 us of hand-out time).
+constexpr uint32_t kTaskCtrStride = 32;                       // words
+constexpr uint32_t kTaskCtrWords = 4 * 8 * kTaskCtrStride;    // [mode][group]
+
 struct Workspace {
     double *partials;         // k_bounds: [256][8] per-block partial results
     uint32_t *tickets;        // self-resetting arrival counters: [0] bounds, [1] cell scan, [2] pair scan
@@ -81,7 +86,7 @@ struct Workspace {
     ulonglong2 *hole_list;    // emit mode: one (start, length) per block
     arp_pair *scratch;        // emit mode: home of positions >= the caller's capacity until k_fixup has closed the holes
     unsigned long long scratch_cap;
-    uint32_t *task_ctr;       // [3 modes][8 block groups]: next wave-task of the group
+    uint32_t *task_ctr;       // [4 modes][8 block groups] x kTaskCtrStride words: next wave-task of the group, one counter per 128-B line
     uint2 *defer_list;        // emit mode: candidates whose classification needs a hydrogen / disulfide probe
     unsigned long long defer_cap;
     uint32_t ncells_cap;

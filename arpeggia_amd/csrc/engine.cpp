@@ -138,7 +138,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.hinfo, cap);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);  // scan_tmp*: >= kScanBlocks + 1
-    A(w.hole_list, 2048); A(w.task_ctr, 32); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
+    A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
     w.defer_cap = std::max<uint64_t>(8 * cap, 1u << 20); A(w.defer_list, w.defer_cap);
 #undef A
     w.n_cap = (uint32_t)cap;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
                                                uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr) {
     __shared__ double s_mn[4][3], s_mx[4][3];
     __shared__ uint32_t s_models[4], s_bad[4];
-    if (threadIdx.x < 32) task_ctr[threadIdx.x] = 0;  // per-call state of the later kernels
+    for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
     if (threadIdx.x < 4) result[threadIdx.x] = 0;
     BoxAcc acc;
     for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {

@@ -30,8 +30,11 @@ constexpr uint32_t kReadAhead = 4;         // LDS reads in flight per lane in th
 constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
 constexpr uint32_t kEmitBlocks = 768;       // emit mode: 3 blocks of 8 waves per CU (6 waves per SIMD)
 constexpr int kEmitWavesPerSimd = 6;         // register budget of the emit kernel: 80 VGPRs
-constexpr uint32_t kGrab = 2;              // wave-tasks drawn per atomic
-constexpr uint32_t kChunkRecords = 2048;    // records per global allocation (one device atomic each)
+constexpr uint32_t kGrab = 1;              // wave-tasks drawn per atomic
+#ifndef ARP_CHUNK_RECORDS
+#define ARP_CHUNK_RECORDS 2048
+#endif
+constexpr uint32_t kChunkRecords = ARP_CHUNK_RECORDS;    // records per global allocation (one device atomic each)
 
 template <int MODE>
 struct WaveLds {                                  // per-wave LDS working set
@@ -98,7 +101,7 @@ DEVFN Slots alloc_records(BlockLds &bl, unsigned long long *g_head, uint32_t n, 
 template <int MODE, bool PROBES>
 DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
                              unsigned long long base, uint32_t emitted, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
-#if defined(ARP_ABLATE) && ARP_ABLATE == 1   // timing ablation: no exact phase at all (results are wrong by construction)
+#if defined(ARP_ABLATE) && ARP_ABLATE != 2   // timing ablations 1, 9: no exact phase at all (results are wrong by construction)
     return (uint32_t)__popcll(__ballot(active));
 #endif
     bool valid = false, swap = false;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
     // kGrab tasks at a time from the group's counter, which evens out the very different costs of surface and core tasks.
     const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
-    uint32_t *ctr = task_ctr + MODE * 8 + group;
+    uint32_t *ctr = task_ctr + (MODE * 8 + group) * kTaskCtrStride;
     uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); emit mode carries them across tasks
 #pragma unroll 1
     for (;;) {
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
             cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
         }
         const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
+#if defined(ARP_ABLATE) && ARP_ABLATE == 9   // timing ablation: task hand-out + home record only (the fixed cost of the launch)
+        if (home.x != 1.2345e30f) continue;
+#endif
         // all five slot windows of this lane up front: ten independent loads in flight instead of five round trips
         uint32_t wlo[5] = {0, 0, 0, 0, 0}, whi[5] = {0, 0, 0, 0, 0};
         if (have) {

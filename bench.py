@@ -114,10 +114,11 @@ def main():
 
     # size the output once (count pass), then everything is allocation-free
     n_pairs = ctx.count(atoms, prm)
-    out = torch.empty((n_pairs, 4), dtype=torch.int32, device=dev)
+    cap = max(n_pairs, 1)  # (diagnostic ablation builds may report no pairs: still run the emit path)
+    out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
 
     def step():
-        ctx.enqueue(atoms, prm, out.data_ptr(), n_pairs)
+        ctx.enqueue(atoms, prm, out.data_ptr(), cap)
 
     for _ in range(args.warmup):
         step()

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 i=0
 for envset in "$@"; do
   i=$((i+1))
-  env $envset timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/ab_${TAG}_$i.json 2> $OUT/ab_${TAG}_$i.err; rc=$?
+  env $envset timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $OUT/ab_${TAG}_$i.json 2> $OUT/ab_${TAG}_$i.err; rc=$?
   echo "== [$envset] rc=$rc"
   python3 -c "
 import json,sys
