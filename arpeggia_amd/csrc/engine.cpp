@@ -139,7 +139,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
-    w.defer_cap = std::max<uint64_t>(8 * cap, 1u << 20); A(w.defer_list, w.defer_cap);
+    w.defer_cap = std::max<uint64_t>(8 * cap, 1u << 20) + (1u << 20); A(w.defer_list, w.defer_cap);  // + one partly used 512-entry chunk per block
 #undef A
     w.n_cap = (uint32_t)cap;
     w.ncells_cap = (uint32_t)ccap;

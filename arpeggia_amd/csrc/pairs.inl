@@ -43,7 +43,10 @@ struct WaveLds {                                  // per-wave LDS working set
 };
 struct BlockLds {
     unsigned long long alloc_state;               // emit mode: current chunk index << 32 | records handed out of it
+    unsigned long long defer_state;               // the same for the deferred-probe list (kDeferChunk entries per chunk)
 };
+constexpr uint32_t kDeferChunk = 512;          // deferred-list entries per global allocation
+constexpr unsigned long long kAllocEmpty = 0xFFFFFFFFull << 32;  // no chunk yet: | chunk size = "exhausted"
 
 // mask = 2 * mask + (d2 <= r2f): one compare and one add-with-carry per prefilter test
 DEVFN void push_pass(uint32_t &mask, float d2, float r2f) {
@@ -68,23 +71,24 @@ DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned lo
 // crosses the end of the chunk takes the rest of it (n0 records at pos0), fetches the next chunk and continues there
 // (pos1); waves that arrive while it does so sleep on the LDS word until the new chunk is published.
 struct Slots { unsigned long long pos0, pos1; uint32_t n0; };
-DEVFN Slots alloc_records(BlockLds &bl, unsigned long long *g_head, uint32_t n, uint32_t lane) {
+template <uint32_t CHUNK>
+DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane) {
     unsigned long long pos0 = 0, pos1 = 0;
     uint32_t n0 = 0;
     if (lane == 0) {
         for (;;) {
-            const unsigned long long old = atomicAdd(&bl.alloc_state, (unsigned long long)n);
+            const unsigned long long old = atomicAdd(&state, (unsigned long long)n);
             const uint32_t used = (uint32_t)old, chunk = (uint32_t)(old >> 32);
-            if (used + n <= kChunkRecords) { pos0 = (unsigned long long)chunk * kChunkRecords + used; n0 = n; break; }
-            if (used <= kChunkRecords) {  // this allocation crosses the end: it alone refills
-                n0 = kChunkRecords - used;
-                pos0 = (unsigned long long)chunk * kChunkRecords + used;
+            if (used + n <= CHUNK) { pos0 = (unsigned long long)chunk * CHUNK + used; n0 = n; break; }
+            if (used <= CHUNK) {  // this allocation crosses the end: it alone refills
+                n0 = CHUNK - used;
+                pos0 = (unsigned long long)chunk * CHUNK + used;
                 const unsigned long long nc = atomicAdd(g_head, 1ull);
-                pos1 = nc * kChunkRecords;
-                __hip_atomic_store(&bl.alloc_state, (nc << 32) | (unsigned long long)(n - n0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pos1 = nc * CHUNK;
+                __hip_atomic_store(&state, (nc << 32) | (unsigned long long)(n - n0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 break;
             }
-            while ((uint32_t)(__hip_atomic_load(&bl.alloc_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == chunk)
+            while ((uint32_t)(__hip_atomic_load(&state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == chunk)
                 __builtin_amdgcn_s_sleep(2);
         }
     }
@@ -101,7 +105,7 @@ DEVFN Slots alloc_records(BlockLds &bl, unsigned long long *g_head, uint32_t n, 
 template <int MODE, bool PROBES>
 DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
                              unsigned long long base, uint32_t emitted, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
-#if defined(ARP_ABLATE) && ARP_ABLATE != 2   // timing ablations 1, 9: no exact phase at all (results are wrong by construction)
+#if defined(ARP_ABLATE) && (ARP_ABLATE == 1 || ARP_ABLATE == 9)   // timing ablations: no exact phase at all (results are wrong by construction)
     return (uint32_t)__popcll(__ballot(active));
 #endif
     bool valid = false, swap = false;
@@ -122,9 +126,17 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
     if (MODE != kCountTasks) {
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (valid) {
+#if defined(ARP_ABLATE) && ARP_ABLATE == 13   // timing ablation: no classification
+            r.w = (a.attr ^ b.attr) & 1u;
+#else
             r.w = classify<PROBES>(in, prm, so.hinfo, s, a, ent.x, b, ent.y, swap, result);
+#endif
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
+#if defined(ARP_ABLATE) && ARP_ABLATE == 14   // timing ablation: no output distance
+            r.z = __float_as_uint((float)s);
+#else
             r.z = __float_as_uint(dist_f32(s));
+#endif
         }
         if (prm.contacts_only) {  // ARP_FLAG_CONTACTS_ONLY: candidates without any interaction are dropped (kDeferKind != 0 stays)
             valid = valid && r.w != 0u;
@@ -138,12 +150,13 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
             if (!PROBES) {
                 const bool defer = valid && r.w == kDeferKind;
                 const unsigned long long dm = __ballot(defer);
-                if (dm) {  // rare: hand the candidate to the deferred pass (one aggregated atomic per wave)
-                    unsigned long long dbase = 0;
-                    if (lane == 0) dbase = atomicAdd(&result[3], (unsigned long long)__popcll(dm));
-                    dbase = __shfl(dbase, 0);
+                if (dm) {  // hand the candidates to the deferred pass.  The list is carved in kDeferChunk-entry chunks by the
+                           // same block-level allocator as the records: one device atomic per wave and batch on result[3]
+                           // serialised hydrogen-rich inputs at ~90 ns each (measured: 2.0 ms on a 150k-atom structure).
+                    const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], (uint32_t)__popcll(dm), lane);
                     if (defer) {
-                        const unsigned long long p = dbase + mbcnt(dm);
+                        const uint32_t dr = mbcnt(dm);
+                        const unsigned long long p = dr < ds.n0 ? ds.pos0 + dr : ds.pos1 + (dr - ds.n0);
                         if (p < tg.defer_cap) tg.defer_list[p] = ent; else atomicOr(&result[1], 8ull);
                     }
                     valid = valid && !defer;
@@ -151,12 +164,21 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
                 }
             }
             const uint32_t n = (uint32_t)__popcll(vm);
+#if defined(ARP_ABLATE) && ARP_ABLATE == 12   // timing ablation: no allocation, no store
+            if (valid && r.w == 0xDEADBEEFu) atomicOr(&result[1], 32ull);
+            if (false) {
+#else
             if (n) {  // compacted, coalesced store of the batch's records straight from registers
-                const Slots sl = alloc_records(bl, &result[2], n, lane);
+#endif
+                const Slots sl = alloc_chunked<kChunkRecords>(bl.alloc_state, &result[2], n, lane);
                 const uint32_t rank = mbcnt(vm);
                 if (valid) {
                     uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
+#if defined(ARP_ABLATE) && ARP_ABLATE == 11   // timing ablation: allocation but no store
+                    if (d && r.w == 0xDEADBEEFu) *d = r;
+#else
                     if (d) *d = r;
+#endif
                 }
             }
         }
@@ -166,8 +188,17 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
 }
 
 // Block epilogue of the emit mode: the unused tail of the block's last chunk is its (one) hole.  Every wave must call it.
-DEVFN void emit_epilogue(BlockLds &bl, ulonglong2 *hole) {
+DEVFN void emit_epilogue(BlockLds &bl, ulonglong2 *hole, const EmitTarget &tg) {
     __syncthreads();
+    {   // unused tail of the block's last deferred-list chunk: sentinels the deferred pass skips
+        const unsigned long long st = bl.defer_state;
+        const uint32_t chunk = (uint32_t)(st >> 32), used = (uint32_t)st;
+        if (chunk != 0xFFFFFFFFu)
+            for (uint32_t k = used + threadIdx.x; k < kDeferChunk; k += blockDim.x) {
+                const unsigned long long p = (unsigned long long)chunk * kDeferChunk + k;
+                if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            }
+    }
     if (threadIdx.x == 0) {
         const unsigned long long st = bl.alloc_state;
         const uint32_t chunk = (uint32_t)(st >> 32), used = (uint32_t)st;
@@ -191,7 +222,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
         if (threadIdx.x == 0) {
             prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
             prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
-            bl.alloc_state = (0xFFFFFFFFull << 32) | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
+            bl.alloc_state = kAllocEmpty | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
+            bl.defer_state = kAllocEmpty | kDeferChunk;
         }
         __syncthreads();
     }
@@ -325,13 +357,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
             wave_lds_fence();
             process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, 0ull, 0u, tg, result, lane);
         }
-        emit_epilogue(bl, hole_list + blockIdx.x);
+        emit_epilogue(bl, hole_list + blockIdx.x, tg);
     }
 }
 
 // The deferred pass of the emit mode: candidates that need a hydrogen or disulfide probe, classified with the probes
 // inline and emitted through the same allocator (its blocks add their own holes to the list k_fixup closes).
-constexpr uint32_t kDeferBlocks = 128;
+constexpr uint32_t kDeferBlocks = 384;       // fills the chip at this kernel's 3 waves per SIMD when the list is long
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms in, const DevParams *dprm, Sorted so, EmitTarget tg,
                                                                          ulonglong2 *hole_list, unsigned long long *result) {
     __shared__ LdsParams prm;
@@ -344,18 +376,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
         if (threadIdx.x == 0) {
             prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
             prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
-            bl.alloc_state = (0xFFFFFFFFull << 32) | kChunkRecords;
+            bl.alloc_state = kAllocEmpty | kChunkRecords;
+            bl.defer_state = kAllocEmpty | kDeferChunk;
         }
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned long long n = min(result[3], tg.defer_cap);
+    const unsigned long long n = min(result[3] * kDeferChunk, tg.defer_cap);  // result[3] counts list chunks
     for (unsigned long long e0 = ((unsigned long long)blockIdx.x * kWavesPerBlock + wave) * 64ull; e0 < n; e0 += (unsigned long long)gridDim.x * kWavesPerBlock * 64ull) {
-        const bool act = e0 + lane < n;
-        const uint2 ent = act ? tg.defer_list[e0 + lane] : make_uint2(0u, 0u);
+        uint2 ent = make_uint2(0xFFFFFFFFu, 0u);
+        if (e0 + lane < n) ent = tg.defer_list[e0 + lane];
+        const bool act = ent.x != 0xFFFFFFFFu;  // chunk tails hold sentinels
         process_batch<kEmit, true>(in, prm, so, wl[wave], bl, ent, act, 0ull, 0u, tg, result, lane);
     }
-    emit_epilogue(bl, hole_list + blockIdx.x);
+    emit_epilogue(bl, hole_list + blockIdx.x, tg);
 }
 
 // Close the holes of the emit pass: with R = records reserved and P = R - sum(holes) valid ones, every hole slot below P
@@ -526,10 +560,10 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
-    static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1900)
+    static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1600)
         const char *e = getenv("ARP_EMIT_BLOCKS");
         const long v = e ? atol(e) : 0;
-        return (v >= 8 && v <= 1900) ? (uint32_t)v : kEmitBlocks;
+        return (v >= 8 && v <= 1600) ? (uint32_t)v : kEmitBlocks;
     }();
     const uint32_t nb = blocks_for(in.n, emit_blocks);
     if (prof) prof->begin("pairs_emit", st);
