@@ -238,11 +238,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
     uint32_t *ctr = task_ctr + (MODE * 8 + group) * kTaskCtrStride;
     uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); emit mode carries them across tasks
+    // The first task of every wave is static (its index among the group's waves): 6144 waves hitting the counters at
+    // launch would be handed their first task one by one.  Later tasks come from the counter, which starts behind them.
+    const uint32_t group_waves = ((gridDim.x - group + n_groups - 1u) / n_groups) * kWavesPerBlock;
+    uint32_t t0 = g_lo + ((blockIdx.x / n_groups) * kWavesPerBlock + wave) * kGrab;
 #pragma unroll 1
-    for (;;) {
-    uint32_t t0 = 0;
-    if (lane == 0) t0 = atomicAdd(ctr, kGrab);
-    t0 = g_lo + __builtin_amdgcn_readfirstlane(t0);
+    for (;; ) {
     if (t0 >= g_hi) break;
     const uint32_t t1 = min(t0 + kGrab, g_hi);
 #pragma unroll 1
@@ -348,6 +349,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
         }
         if ((MODE == kCountTasks || MODE == kCountContacts) && lane == 0) task_count[t] = emitted;
     }
+    uint32_t nxt = 0;
+    if (lane == 0) nxt = atomicAdd(ctr, kGrab);
+    t0 = g_lo + group_waves * kGrab + __builtin_amdgcn_readfirstlane(nxt);
     }
     if (MODE == kEmit) {
         if (qlen) {
