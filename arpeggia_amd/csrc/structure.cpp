@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <array>
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,19 +59,42 @@ static const ClassSpec kResidueSpecs[] = {
     {"CYS", "SG", ARP_ATTR_CYS_SG},
     {"ARG", "NE CZ NH1 NH2", ARP_ATTR_POS_RESN}, {"HIS", "CG ND1 CE1 NE2 CD2", ARP_ATTR_POS_RESN}, {"LYS", "NZ", ARP_ATTR_POS_RESN}};
 
-using ClassMap = std::unordered_map<std::string, uint32_t>;
+// (residue name, atom name) -> attribute bits.  Keys are the two names packed into one 64-bit word (4 + 4 bytes, NUL padded):
+// every name in the tables is at most 3 / 4 characters, so a longer input name simply never matches, as in the reference's
+// string `matches!`.
+using ClassMap = std::unordered_map<uint64_t, uint32_t>;
+static bool pack4(const char *s, uint32_t *out) {
+    const size_t n = strlen(s);
+    if (n > 4) return false;
+    uint32_t v = 0;
+    memcpy(&v, s, n);
+    *out = v;
+    return true;
+}
+static bool pack_key(const char *res, const char *atom, uint64_t *key) {
+    uint32_t r, a;
+    if (!pack4(res, &r) || !pack4(atom, &a)) return false;
+    *key = ((uint64_t)r << 32) | a;
+    return true;
+}
 template <size_t N>
 static ClassMap build_map(const ClassSpec (&specs)[N]) {
     ClassMap m;
     for (const ClassSpec &s : specs) {
         std::istringstream is(s.atoms);
         std::string a;
-        while (is >> a) m[std::string(s.res) + ":" + a] |= s.bit;
+        while (is >> a) {
+            uint64_t key = 0;
+            pack_key(s.res, a.c_str(), &key);
+            m[key] |= s.bit;
+        }
     }
     return m;
 }
 static uint32_t lookup(const ClassMap &m, const char *res, const char *atom) {
-    auto it = m.find(std::string(res) + ":" + atom);
+    uint64_t key;
+    if (!pack_key(res, atom, &key)) return 0u;
+    auto it = m.find(key);
     return it == m.end() ? 0u : it->second;
 }
 
@@ -100,52 +124,114 @@ struct Record {
     uint32_t res_ord, res_id;  // hierarchy == 1 only
 };
 
-static std::string cut(const std::string &line, size_t c0, size_t c1, bool upper) {  // 1-based inclusive columns, trimmed
-    if (line.size() < c0) return "";
-    std::string s = line.substr(c0 - 1, std::min(c1, line.size()) - (c0 - 1));
-    size_t a = s.find_first_not_of(" \t"), b = s.find_last_not_of(" \t");
-    if (a == std::string::npos) return "";
-    s = s.substr(a, b - a + 1);
-    if (upper) for (char &ch : s) ch = (char)toupper((unsigned char)ch);
-    return s;
-}
 static void put(char *dst, size_t cap, const std::string &s) {
     memset(dst, 0, cap);
     memcpy(dst, s.data(), std::min(cap - 1, s.size()));
 }
 
-static arp_status read_pdb(const char *path, std::vector<Record> *out) {
-    std::ifstream f(path);
-    if (!f) { set_error("cannot open '%s'", path); return ARP_ERR_IO; }
-    std::string line;
-    int32_t model_serial = 0;
-    while (std::getline(f, line)) {
-        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-        if (line.compare(0, 5, "MODEL") == 0 && (line.size() == 5 || line[5] == ' ')) { model_serial = (int32_t)strtol(cut(line, 7, 14, false).c_str(), nullptr, 10); continue; }
-        bool atom = line.compare(0, 6, "ATOM  ") == 0, het = line.compare(0, 6, "HETATM") == 0;
-        if ((!atom && !het) || line.size() < 54) continue;
-        Record r{};
-        r.serial = (int32_t)strtol(cut(line, 7, 11, false).c_str(), nullptr, 10);
-        put(r.name, sizeof r.name, cut(line, 13, 16, true));
-        put(r.altloc, sizeof r.altloc, cut(line, 17, 17, false));
-        put(r.resn, sizeof r.resn, cut(line, 18, 20, true));
-        put(r.chain, sizeof r.chain, cut(line, 22, 22, false));
-        r.resi = (int32_t)strtol(cut(line, 23, 26, false).c_str(), nullptr, 10);
-        put(r.icode, sizeof r.icode, cut(line, 27, 27, false));
-        r.x = strtod(cut(line, 31, 38, false).c_str(), nullptr);
-        r.y = strtod(cut(line, 39, 46, false).c_str(), nullptr);
-        r.z = strtod(cut(line, 47, 54, false).c_str(), nullptr);
-        std::string occ = cut(line, 55, 60, false);
-        r.occ = occ.empty() ? 1.0 : strtod(occ.c_str(), nullptr);
-        std::string el = cut(line, 77, 78, true);
-        if (el.empty()) {  // no element column: first letter of the atom name
-            const char *p = r.name;
-            while (*p && isdigit((unsigned char)*p)) p++;
-            el = *p ? std::string(1, *p) : "X";
+// Fixed-column fields straight out of the file buffer (no per-field std::string: a 10k-atom file has 130k fields).
+struct Field { const char *b, *e; };  // trimmed [b, e)
+static inline Field field(const char *line, size_t len, size_t c0, size_t c1) {  // 1-based inclusive columns
+    if (len < c0) return {line, line};
+    const char *b = line + (c0 - 1), *e = line + std::min(c1, len);
+    while (b < e && (*b == ' ' || *b == '\t')) b++;
+    while (e > b && (e[-1] == ' ' || e[-1] == '\t')) e--;
+    return {b, e};
+}
+static inline void put_field(char *dst, size_t cap, Field f, bool upper) {
+    memset(dst, 0, cap);
+    size_t n = std::min(cap - 1, (size_t)(f.e - f.b));
+    for (size_t k = 0; k < n; k++) { const char c = f.b[k]; dst[k] = (upper && c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }  // "C"-locale toupper
+}
+static inline long field_long(Field f) {  // strtol(base 10) on the trimmed field
+    {
+        const char *q = f.b;
+        bool neg = false;
+        if (q < f.e && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
+        long v = 0;
+        int digits = 0;
+        for (; q < f.e && *q >= '0' && *q <= '9' && digits < 18; q++, digits++) v = v * 10 + (*q - '0');
+        if (digits < 18) return neg ? -v : v;  // like strtol: stops at the first non-digit, 0 when there is none
+    }
+    char tmp[24];
+    size_t n = std::min(sizeof tmp - 1, (size_t)(f.e - f.b));
+    memcpy(tmp, f.b, n); tmp[n] = 0;
+    return strtol(tmp, nullptr, 10);
+}
+static inline double field_double(Field f) {
+    // Plain decimals ("-12.345", the only form PDB coordinate columns hold): digits / 10^k with both operands exact doubles is
+    // correctly rounded, i.e. the value strtod returns.  Anything else (exponents, inf/nan, > 15 digits) goes to strtod.
+    {
+        static const double kPow10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+        const char *q = f.b;
+        bool neg = false;
+        if (q < f.e && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
+        uint64_t m = 0;
+        int digits = 0, frac = 0;
+        bool dot = false, ok = q < f.e;
+        for (; q < f.e; q++) {
+            if (*q >= '0' && *q <= '9') { m = m * 10 + (uint64_t)(*q - '0'); digits++; if (dot) frac++; }
+            else if (*q == '.' && !dot) dot = true;
+            else { ok = false; break; }
         }
-        put(r.elem, sizeof r.elem, el);
+        if (ok && digits > 0 && digits <= 15) {
+            const double v = (double)m / kPow10[frac];
+            return neg ? -v : v;
+        }
+    }
+    char tmp[40];
+    size_t n = std::min(sizeof tmp - 1, (size_t)(f.e - f.b));
+    memcpy(tmp, f.b, n); tmp[n] = 0;
+    return strtod(tmp, nullptr);
+}
+
+static arp_status read_pdb(const char *path, std::vector<Record> *out) {
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { set_error("cannot open '%s'", path); return ARP_ERR_IO; }
+    std::string buf;
+    {
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, fp)) > 0) buf.append(chunk, got);
+        fclose(fp);
+    }
+    out->reserve(buf.size() / 81 + 16);
+    int32_t model_serial = 0;
+    const char *p = buf.data(), *end = p + buf.size();
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *line = p, *le = nl ? nl : end;
+        p = nl ? nl + 1 : end;
+        while (le > line && (le[-1] == '\r' || le[-1] == '\n')) le--;
+        const size_t len = (size_t)(le - line);
+        if (len >= 5 && memcmp(line, "MODEL", 5) == 0 && (len == 5 || line[5] == ' ')) { model_serial = (int32_t)field_long(field(line, len, 7, 14)); continue; }
+        if (len < 54) continue;
+        const bool atom = memcmp(line, "ATOM  ", 6) == 0, het = memcmp(line, "HETATM", 6) == 0;
+        if (!atom && !het) continue;
+        out->emplace_back();
+        Record &r = out->back();
+        memset(&r, 0, sizeof r);
+        r.serial = (int32_t)field_long(field(line, len, 7, 11));
+        put_field(r.name, sizeof r.name, field(line, len, 13, 16), true);
+        put_field(r.altloc, sizeof r.altloc, field(line, len, 17, 17), false);
+        put_field(r.resn, sizeof r.resn, field(line, len, 18, 20), true);
+        put_field(r.chain, sizeof r.chain, field(line, len, 22, 22), false);
+        r.resi = (int32_t)field_long(field(line, len, 23, 26));
+        put_field(r.icode, sizeof r.icode, field(line, len, 27, 27), false);
+        r.x = field_double(field(line, len, 31, 38));
+        r.y = field_double(field(line, len, 39, 46));
+        r.z = field_double(field(line, len, 47, 54));
+        const Field occ = field(line, len, 55, 60);
+        r.occ = occ.b == occ.e ? 1.0 : field_double(occ);
+        const Field el = field(line, len, 77, 78);
+        if (el.b == el.e) {  // no element column: first letter of the atom name
+            const char *q = r.name;
+            while (*q && isdigit((unsigned char)*q)) q++;
+            r.elem[0] = *q ? *q : 'X';
+        } else {
+            put_field(r.elem, sizeof r.elem, el, true);
+        }
         r.model_serial = model_serial;
-        out->push_back(r);
     }
     return ARP_OK;
 }
@@ -241,22 +327,32 @@ static arp_status build(const std::vector<Record> &recs, int hierarchy, bool dro
     if (hierarchy == 0) {
         // pdbtbx add_atom: existing chain by id, existing residue by (serial, insertion), existing conformer by (name, altloc)
         std::unordered_map<std::string, uint32_t> chain_of, res_of;
-        int32_t cur_serial = 0; int cur_model = -1;
+        int32_t cur_serial = 0; int cur_model = -1, prev_model = -1;
+        uint32_t prev_chain = 0, prev_res = 0;
+        bool have_prev = false, have_res = false;
         for (size_t i = 0; i < nrec; i++) {
             const Record &r = recs[i];
             if (cur_model < 0 || r.model_serial != cur_serial) { cur_model++; cur_serial = r.model_serial; }
-            std::string ck = std::to_string(cur_model) + "|" + r.chain;
-            auto ci = chain_of.find(ck);
-            if (ci == chain_of.end()) { ci = chain_of.emplace(ck, (uint32_t)chains.size()).first; chains.push_back({(uint32_t)cur_model, cur_serial, r.chain}); }
-            std::string rk = std::to_string(ci->second) + "|" + std::to_string(r.resi) + "|" + r.icode;
-            auto ri = res_of.find(rk);
-            if (ri == res_of.end()) { ri = res_of.emplace(rk, (uint32_t)res.size()).first; BuildRes b; b.chain = ci->second; b.resi = r.resi; b.icode = r.icode; res.push_back(b); }
-            BuildRes &br = res[ri->second];
+            // consecutive records almost always stay in the same chain and residue: the keyed lookups run per change only
+            if (!have_prev || cur_model != prev_model || memcmp(r.chain, recs[i - 1].chain, sizeof r.chain) != 0) {
+                std::string ck = std::to_string(cur_model) + "|" + r.chain;
+                auto ci = chain_of.find(ck);
+                if (ci == chain_of.end()) { ci = chain_of.emplace(ck, (uint32_t)chains.size()).first; chains.push_back({(uint32_t)cur_model, cur_serial, r.chain}); }
+                prev_chain = ci->second; prev_model = cur_model; have_res = false;
+            }
+            if (!have_res || r.resi != recs[i - 1].resi || memcmp(r.icode, recs[i - 1].icode, sizeof r.icode) != 0) {
+                std::string rk = std::to_string(prev_chain) + "|" + std::to_string(r.resi) + "|" + r.icode;
+                auto ri = res_of.find(rk);
+                if (ri == res_of.end()) { ri = res_of.emplace(rk, (uint32_t)res.size()).first; BuildRes b; b.chain = prev_chain; b.resi = r.resi; b.icode = r.icode; res.push_back(b); }
+                prev_res = ri->second; have_res = true;
+            }
+            have_prev = true;
+            BuildRes &br = res[prev_res];
             uint32_t k = 0;
             for (; k < br.confs.size(); k++) if (br.confs[k].name == r.resn && br.confs[k].altloc == r.altloc) break;
             if (k == br.confs.size()) br.confs.push_back({r.resn, r.altloc, k});
             br.atoms.push_back({k, (uint32_t)i});
-            rec_res[i] = ri->second;
+            rec_res[i] = prev_res;
         }
         for (BuildRes &b : res) {
             b.name = b.confs[0].name;  // Residue::name(): Some iff all conformers agree
@@ -316,6 +412,8 @@ static arp_status build(const std::vector<Record> &recs, int hierarchy, bool dro
     if (s->chain_ids.size() > 65535 || (chains.empty() ? 0u : chains.back().model_idx) > 65535) { set_error("too many chains / models"); return ARP_ERR_BAD_INPUT; }
     std::unordered_map<std::string, uint16_t> rank;
     for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
+    std::vector<uint16_t> rank_of_chain(chains.size());
+    for (size_t c = 0; c < chains.size(); c++) rank_of_chain[c] = rank[chains[c].id];
     for (size_t k = 0; k < n; k++) {
         const Record &r = recs[keep_idx[k]];
         const BuildRes &br = res[rec_res[keep_idx[k]]];
@@ -326,7 +424,7 @@ static arp_status build(const std::vector<Record> &recs, int hierarchy, bool dro
         s->res_ord[k] = hierarchy ? r.res_ord : ord[rec_res[keep_idx[k]]];
         s->res_id[k] = new_id[rec_res[keep_idx[k]]];
         s->atom_chain[k] = br.chain;
-        s->chain_rank[k] = rank[r.chain];
+        s->chain_rank[k] = rank_of_chain[br.chain];
         s->model[k] = (uint16_t)chains[br.chain].model_idx;
         int cls = element_class(r.elem);
         if (cls < 0) { set_error("atom %d (%s %s): element '%s' has no radii in this build", r.serial, r.resn, r.name, r.elem); return ARP_ERR_BAD_INPUT; }
@@ -339,8 +437,13 @@ static arp_status build(const std::vector<Record> &recs, int hierarchy, bool dro
         if (!res[r].keep) continue;
         ResidueInfo &ri = s->residues[new_id[r]];
         ri.chain = res[r].chain; ri.resi = res[r].resi; ri.icode = res[r].icode; ri.name = res[r].name; ri.ord = ord[r];
-        std::vector<std::pair<uint32_t, uint32_t>> at = res[r].atoms;
-        std::stable_sort(at.begin(), at.end(), [](auto &a, auto &b) { return a.first < b.first; });
+        std::vector<std::pair<uint32_t, uint32_t>> sorted_atoms;
+        if (res[r].confs.size() > 1) {  // several conformers: conformer ordinal first, input order inside
+            sorted_atoms = res[r].atoms;
+            std::stable_sort(sorted_atoms.begin(), sorted_atoms.end(), [](auto &a, auto &b) { return a.first < b.first; });
+        }
+        const std::vector<std::pair<uint32_t, uint32_t>> &at = res[r].confs.size() > 1 ? sorted_atoms : res[r].atoms;
+        ri.atoms.reserve(at.size());
         for (auto &pr : at) {
             uint32_t a = new_atom[pr.second];
             if (a == ARP_NONE) continue;
@@ -426,10 +529,14 @@ extern "C" arp_status arp_structure_load(const char *path, int32_t ignore_zero_o
     size_t dot = p.find_last_of('.');
     if (dot != std::string::npos) ext = p.substr(dot + 1);
     for (char &c : ext) c = (char)tolower((unsigned char)c);
+    auto T0 = std::chrono::steady_clock::now();
     arp_status st = (ext == "cif" || ext == "mmcif") ? read_mmcif(path, &recs) : read_pdb(path, &recs);
     if (st != ARP_OK) return st;
+    auto T1 = std::chrono::steady_clock::now();
     arp_structure *s = new arp_structure();
     st = build(recs, 0, ignore_zero_occupancy != 0, s);
+    auto T2 = std::chrono::steady_clock::now();
+    if (getenv("ARP_TIMING")) fprintf(stderr, "read %.3f ms build %.3f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count());
     if (st != ARP_OK) { delete s; return st; }
     *out = s;
     return ARP_OK;

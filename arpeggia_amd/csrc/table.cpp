@@ -4,7 +4,10 @@
 // assembled here on the host in round 1 (SURVEY.md 8f rows f1/f2 move them to the device next).
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -171,8 +174,8 @@ struct arp_table {
 };
 
 namespace {
-struct Entity {  // structs.rs:55-70
-    std::string chain, resn, insertion, altloc, atomn;
+struct Entity {  // structs.rs:55-70; fixed NUL-padded names (the widths of the table's string columns): rows stay POD
+    char chain[8], resn[8], atomn[8], insertion[4], altloc[4];
     int32_t resi = 0, atomi = 0, atom = -1;
     uint16_t chain_rank = 0;
     int64_t sc_plane = -1;
@@ -187,6 +190,15 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
                                        arp_table **out) {
     if (!s || !out || !groups) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     *out = nullptr;
+    // ARP_TIMING=1: per-stage wall times on stderr (diagnostic)
+    const bool timing = getenv("ARP_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  get_contacts %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     // InteractionComplex::new (complex.rs:36-68)
     arp_atoms view;
     arp_status st = arp_structure_atoms(s, groups, &view);
@@ -208,6 +220,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     }
     for (PlaneEntry &e : rings) { e.chain_rank = rank[e.chain]; e.in_l = chain_l[e.chain_rank]; e.in_r = chain_r[e.chain_rank]; }
 
+    lap("planes + groups");
     // get_atomic_contacts (complex.rs:189-299): the GPU hot path
     arp_params prm;
     arp_default_params(&prm);
@@ -216,14 +229,17 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     arp_pairs pairs{};
     st = arp_contacts_atomic(ctx, &view, &prm, ARP_MEM_HOST, &pairs);
     if (st != ARP_OK) return st;
+    lap("atomic pairs (GPU)");
 
     // per-atom side-chain plane lookup (the join key of mod.rs:100-110 plus resn, as in collect_sc_stats)
     std::vector<int64_t> atom_sc(s->n, -1);
     {
-        std::vector<int64_t> cache_res;  // per (residue, altloc) lookups are repeated per atom; memoise on residue id + altloc
-        std::map<std::pair<uint32_t, std::string>, int64_t> memo;
+        // per (residue, altloc) lookups are repeated per atom: memoise on residue id + the (<= 3 byte) altloc
+        std::unordered_map<uint64_t, int64_t> memo;
         for (size_t a = 0; a < s->n; a++) {
-            auto key = std::make_pair(s->res_id[a], s->altloc.str(a));
+            uint32_t alt = 0;
+            memcpy(&alt, s->altloc.at(a), 4);
+            const uint64_t key = ((uint64_t)s->res_id[a] << 32) | alt;
             auto it = memo.find(key);
             if (it == memo.end()) {
                 auto f = sc_idx.find(PlaneKey{s->model_serial[a], s->chain.str(a), s->resi[a], s->icode.str(a), s->altloc.str(a), s->res_resn.str(a)});
@@ -234,13 +250,16 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     }
     auto entity_from_atom = [&](uint32_t a) {  // structs.rs:109-119
         Entity e;
-        e.chain = s->chain.str(a); e.resn = s->res_resn.str(a); e.insertion = s->icode.str(a); e.altloc = s->altloc.str(a); e.atomn = s->name.str(a);
+        memcpy(e.chain, s->chain.at(a), 8); memcpy(e.resn, s->res_resn.at(a), 8); memcpy(e.atomn, s->name.at(a), 8);
+        memcpy(e.insertion, s->icode.at(a), 4); memcpy(e.altloc, s->altloc.at(a), 4);
         e.resi = s->resi[a]; e.atomi = s->serial[a]; e.atom = (int32_t)a; e.chain_rank = s->chain_rank[a]; e.sc_plane = atom_sc[a];
         return e;
     };
     auto entity_from_ring = [&](const PlaneEntry &r) {  // complex.rs:334-342
         Entity e;
-        e.chain = r.chain; e.resn = r.resn; e.insertion = r.icode; e.altloc = r.altloc; e.atomn = "Ring"; e.resi = r.resi; e.atomi = 0; e.atom = -1;
+        auto put = [](char *dst, size_t cap, const std::string &v) { memset(dst, 0, cap); memcpy(dst, v.data(), std::min(cap - 1, v.size())); };
+        put(e.chain, 8, r.chain); put(e.resn, 8, r.resn); put(e.atomn, 8, "Ring"); put(e.insertion, 4, r.icode); put(e.altloc, 4, r.altloc);
+        e.resi = r.resi; e.atomi = 0; e.atom = -1;
         e.chain_rank = r.chain_rank;
         auto f = sc_idx.find(PlaneKey{r.model_serial, r.chain, r.resi, r.icode, r.altloc, r.resn});
         e.sc_plane = f == sc_idx.end() ? -1 : (int64_t)f->second;
@@ -255,6 +274,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
             if (p.kind & (1u << b)) rows.push_back(Row{(uint32_t)s->model_serial[p.i], b, (double)p.dist, entity_from_atom(p.i), entity_from_atom(p.j)});
     }
     arp_pairs_free(&pairs);
+    lap("atom rows");
 
     // get_ring_atom_contacts (complex.rs:301-352) + find_cation_pi (aromatic.rs:14-29)
     const double r2 = dist_cutoff * dist_cutoff;
@@ -295,6 +315,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
             if (code >= 0) rows.push_back(Row{(uint32_t)k1.model_serial, code, dist, entity_from_ring(k1), entity_from_ring(k2)});
         }
     }
+    lap("ring rows");
     // sort (mod.rs:120-134): model, from_chain, to_chain, from_resi, from_altloc, from_atomi, to_resi, to_altloc, to_atomi, interaction
     int name_rank[ARP_N_INTERACTIONS];
     {
@@ -311,18 +332,19 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
         if (a.from.chain_rank != b.from.chain_rank) return a.from.chain_rank < b.from.chain_rank;
         if (a.to.chain_rank != b.to.chain_rank) return a.to.chain_rank < b.to.chain_rank;
         if (a.from.resi != b.from.resi) return a.from.resi < b.from.resi;
-        if (int c = a.from.altloc.compare(b.from.altloc)) return c < 0;
+        if (int c = strcmp(a.from.altloc, b.from.altloc)) return c < 0;
         if (a.from.atomi != b.from.atomi) return a.from.atomi < b.from.atomi;
         if (a.to.resi != b.to.resi) return a.to.resi < b.to.resi;
-        if (int c = a.to.altloc.compare(b.to.altloc)) return c < 0;
+        if (int c = strcmp(a.to.altloc, b.to.altloc)) return c < 0;
         if (a.to.atomi != b.to.atomi) return a.to.atomi < b.to.atomi;
         if (a.interaction != b.interaction) return name_rank[a.interaction] < name_rank[b.interaction];
         // the reference's sort is unstable on full ties; break them deterministically
-        if (int c = a.from.insertion.compare(b.from.insertion)) return c < 0;
-        if (int c = a.to.insertion.compare(b.to.insertion)) return c < 0;
+        if (int c = strcmp(a.from.insertion, b.from.insertion)) return c < 0;
+        if (int c = strcmp(a.to.insertion, b.to.insertion)) return c < 0;
         if (a.distance != b.distance) return a.distance < b.distance;
         return ia < ib;
     });
+    lap("sort");
     arp_table *t = new arp_table();
     const size_t n = rows.size();
     t->n = n;
@@ -333,11 +355,11 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     for (size_t k = 0; k < n; k++) {
         const Row &r = rows[order[k]];
         t->model[k] = r.model; t->interaction[k] = r.interaction; t->distance[k] = (float)r.distance;  // mod.rs:148
-        t->from_chain.set(k, r.from.chain.c_str()); t->from_resn.set(k, r.from.resn.c_str()); t->from_atomn.set(k, r.from.atomn.c_str());
-        t->from_insertion.set(k, r.from.insertion.c_str()); t->from_altloc.set(k, r.from.altloc.c_str());
+        t->from_chain.set(k, r.from.chain); t->from_resn.set(k, r.from.resn); t->from_atomn.set(k, r.from.atomn);
+        t->from_insertion.set(k, r.from.insertion); t->from_altloc.set(k, r.from.altloc);
         t->from_resi[k] = r.from.resi; t->from_atomi[k] = r.from.atomi; t->from_atom[k] = r.from.atom;
-        t->to_chain.set(k, r.to.chain.c_str()); t->to_resn.set(k, r.to.resn.c_str()); t->to_atomn.set(k, r.to.atomn.c_str());
-        t->to_insertion.set(k, r.to.insertion.c_str()); t->to_altloc.set(k, r.to.altloc.c_str());
+        t->to_chain.set(k, r.to.chain); t->to_resn.set(k, r.to.resn); t->to_atomn.set(k, r.to.atomn);
+        t->to_insertion.set(k, r.to.insertion); t->to_altloc.set(k, r.to.altloc);
         t->to_resi[k] = r.to.resi; t->to_atomi[k] = r.to.atomi; t->to_atom[k] = r.to.atom;
         // collect_sc_stats (complex.rs:137-174): res1 = ligand residue, res2 = receptor residue
         if (r.from.sc_plane >= 0 && r.to.sc_plane >= 0) {
@@ -348,6 +370,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
             t->sc_angle[k] = (float)point_angle(p1, p2.c);
         }
     }
+    lap("columns + sc stats");
     *out = t;
     return ARP_OK;
 }
