@@ -36,6 +36,8 @@ struct GridParams {
     uint32_t bad;         // non-finite coordinate seen
     float prefilter_margin;
     uint32_t pad;
+    double mx, my, mz;    // box midpoint: the f32 prefilter records are relative to it (halves their magnitude)
+    double r2m;           // prefilter threshold on d^2 in f64: r2 + storage margin + dot-form margin
 };
 
 // Device view of the caller's SoA (all device pointers).
@@ -56,7 +58,8 @@ struct __attribute__((aligned(16))) Fat {
 
 // Cell-sorted copy of the heavy atoms (slot order: x-major cells, atoms of a cell in ascending input index).
 struct Sorted {
-    float4 *rec;          // {x-ox, y-oy, z-oz as f32, bits(cell id)}  -- prefilter operand, 16 B
+    float4 *rec;          // {x-mx, y-my, z-mz as f32, |.|^2 of those three}  -- prefilter operand, 16 B
+    uint32_t *cell;       // cell id of the slot (the home side of a task derives its windows from it)
     Fat *fat;
     uint2 *hinfo;         // [begin, end) of the residue's hydrogens in res_h_idx
 };

@@ -41,6 +41,12 @@ DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, 
     const double margin = 4e-6 * (prm->r2 + fabs(cutoff) * M) + 1e-6;
     g->prefilter_margin = (float)margin;
     prm->r2f = __double2float_ru(prm->r2 + margin);
+    // The test is evaluated as |n|^2 - 2 n.h <= thr - |h|^2 (3 FMAs instead of 3 subtractions + 3 multiply-adds) on records
+    // centred on the box midpoint, |coordinate| <= C = M / 2.  Rounding of the stored |n|^2 and of the three FMAs moves the
+    // left side by at most 24 * 2^-24 * C^2 (DESIGN.md "Prefilter margin"); twice that is added to the threshold.
+    for (int k = 0; k < 3; k++) (&g->mx)[k] = lo[k] + 0.5 * ext[k];
+    const double C = 0.5 * M;
+    g->r2m = prm->r2 + margin + 3e-6 * C * C;
 }
 
 // Bounding box in two launches: per-block partial results with plain stores, then one block reduces them and sizes the grid.
@@ -264,7 +270,9 @@ constexpr uint32_t kAttrResHasH = 0x80000000u;  // internal: the atom's residue 
 
 DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so, uint32_t i, uint32_t c, uint32_t d) {
     const double x = in.x[i], y = in.y[i], z = in.z[i];
-    so.rec[d] = make_float4((float)(x - gp->ox), (float)(y - gp->oy), (float)(z - gp->oz), __uint_as_float(c));
+    const float fx = (float)(x - gp->mx), fy = (float)(y - gp->my), fz = (float)(z - gp->mz);
+    so.rec[d] = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
+    so.cell[d] = c;
     Fat f;
     f.x = x; f.y = y; f.z = z;
     f.attr = in.attr[i] & ~kAttrResHasH; f.res_ord = in.res_ord[i]; f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i;

@@ -172,21 +172,25 @@ DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *h
 }
 
 // (float) of the correctly rounded f64 square root -- what the reference stores in the table (mod.rs:148) -- without the
-// library sqrt: f32 rsq seed, two coupled Newton steps and a residual correction in f64 leave < 2 ulp(f64) of error, which
-// cannot change the f32 rounding unless the result sits within a few f64 ulps of an f32 rounding boundary; only then
-// (probability ~1e-8) the exact library routine runs.
+// library sqrt on the common path.  f32 rsq seed r (relative error e0 <= 2^-22.4), one coupled Newton step in f64
+// (y1 = sqrt(s)(1 - e0^2), h1 = (1 - e0^2) / (2 sqrt(s))) and the residual correction y2 = y1 + (s - y1^2) h1, whose error
+// is O(e0^4) plus the rounding of the last FMA: < 2 ulp(f64).  That cannot change the f32 rounding unless y2 sits within a
+// few f64 ulps of an f32 rounding boundary (probability ~1e-8 per pair); only then, and for degenerate s, the exact library
+// routine runs -- behind a WAVE-UNIFORM branch: left to the compiler, both paths were evaluated for every pair.
 DEVFN float dist_f32(double s) {
-    if (!(s > 1e-30 && s < 1e30)) return (float)sqrt(s);
     const double r = (double)__frsqrt_rn((float)s);
     double y = s * r, h = 0.5 * r;
-    double e = __fma_rn(-h, y, 0.5);
-    y = __fma_rn(y, e, y); h = __fma_rn(h, e, h);
-    e = __fma_rn(-h, y, 0.5);
+    const double e = __fma_rn(-h, y, 0.5);
     y = __fma_rn(y, e, y); h = __fma_rn(h, e, h);
     y = __fma_rn(__fma_rn(-y, y, s), h, y);
     const uint32_t low = (uint32_t)__double_as_longlong(y) & 0x1FFFFFFFu;  // the 29 bits a cast to f32 drops
-    if (low - (0x10000000u - 16u) <= 32u) return (float)sqrt(s);             // near the midpoint: decide exactly
-    return (float)y;
+    const bool exact = !(s > 1e-30 && s < 1e30) | (low - (0x10000000u - 16u) <= 32u);  // degenerate, or near the midpoint
+    float out = (float)y;
+    if (__ballot(exact) != 0ull) {
+        asm volatile("" ::: "memory");  // keep this a branch (no speculation of the long sequence)
+        if (exact) out = (float)sqrt(s);
+    }
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------- pair search + launch

@@ -49,8 +49,8 @@ constexpr uint32_t kDeferChunk = 512;          // deferred-list entries per glob
 constexpr unsigned long long kAllocEmpty = 0xFFFFFFFFull << 32;  // no chunk yet: | chunk size = "exhausted"
 
 // mask = 2 * mask + (d2 <= r2f): one compare and one add-with-carry per prefilter test
-DEVFN void push_pass(uint32_t &mask, float d2, float r2f) {
-    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2f) : "vcc");
+DEVFN void push_pass(uint32_t &mask, float d2, float thr) {
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(thr) : "vcc");
 }
 
 struct EmitTarget {  // positions >= capacity spill into the engine's scratch so that a buffer of exactly P records suffices
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
-    const float r2f = dprm->r2f;
+    const double r2m = gp->r2m;
     WaveLds<MODE> &w = wl[wave];
     // Task distribution: blocks b and b+8 share an XCD (and its private L2), so block group (b mod 8) owns one contiguous
     // eighth of the task range -- the windows its waves stage come out of that L2 -- and inside a group the waves draw
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
         uint32_t cx = 0, cy = 0, cz = 0;
         if (have) {
             home = so.rec[a];
-            uint32_t c = __float_as_uint(home.w);
+            uint32_t c = so.cell[a];
             cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
         }
         const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
@@ -277,6 +277,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
             }
         }
         const unsigned long long base = (MODE == kFillOrdered) ? task_base[t] : 0ull;
+        // per-lane constants of the prefilter: -2 h (exact in f32) and the threshold r2m - |h|^2, rounded up
+        const float3 hm2 = make_float3(-2.0f * home.x, -2.0f * home.y, -2.0f * home.z);
+        const float thr = __double2float_ru(r2m - ((double)home.x * home.x + (double)home.y * home.y + (double)home.z * home.z));
         uint32_t emitted = 0;
 #pragma unroll 1
         for (int k = 0; k < 5; k++) {
@@ -306,15 +309,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
                     // kReadAhead LDS reads in flight, then their tests: issued one by one, every test would pay the full LDS latency
 #pragma unroll
                     for (uint32_t u0 = 0; u0 < kBlock; u0 += kReadAhead) {
-                        float rx[kReadAhead], ry[kReadAhead], rz[kReadAhead];
+                        float rx[kReadAhead], ry[kReadAhead], rz[kReadAhead], rw[kReadAhead];
 #pragma unroll
-                        for (uint32_t u = 0; u < kReadAhead; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; }
+                        for (uint32_t u = 0; u < kReadAhead; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; rw[u] = r.w; }
 #pragma unroll
-                        for (uint32_t u = 0; u < kReadAhead; ++u) {
-                            const float dx = rx[u] - home.x, dy = ry[u] - home.y, dz = rz[u] - home.z;
-                            push_pass(mask, __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz)), r2f);
-                        }
+                        for (uint32_t u = 0; u < kReadAhead; ++u)  // |n|^2 - 2 n.h against thr = r2m - |h|^2: 5 VALU per test
+                            push_pass(mask, __fmaf_rn(rz[u], hm2.z, __fmaf_rn(ry[u], hm2.y, __fmaf_rn(rx[u], hm2.x, rw[u]))), thr);
                     }
+#if defined(ARP_PAD)   // timing probe: ARP_PAD extra VALU instructions per block (is the kernel VALU-issue bound?)
+                    {
+                        float pa = home.x, pb = home.y;
+#pragma unroll
+                        for (int q = 0; q < ARP_PAD / 2; q++) asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(pa), "+v"(pb));
+                        if (pa == 1.2345f && pb == 5.4321f) mask ^= 1u;
+                    }
+#endif
                     const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
                     if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);
                     // Compaction: one round per surviving test of the busiest lane; every round appends <= 64 entries
