@@ -71,32 +71,33 @@ DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned lo
 // crosses the end of the chunk takes the rest of it (n0 records at pos0), fetches the next chunk and continues there
 // (pos1); waves that arrive while it does so sleep on the LDS word until the new chunk is published.
 struct Slots { unsigned long long pos0, pos1; uint32_t n0; };
+DEVFN unsigned long long wave_first_u64(unsigned long long v) {
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+// Only the LDS atomic itself runs in lane 0; everything derived from its (broadcast) result is wave-uniform, so the
+// position arithmetic lands on the scalar unit instead of costing vector issue slots for one live lane.
 template <uint32_t CHUNK>
 DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane) {
-    unsigned long long pos0 = 0, pos1 = 0;
-    uint32_t n0 = 0;
-    if (lane == 0) {
-        for (;;) {
-            const unsigned long long old = atomicAdd(&state, (unsigned long long)n);
-            const uint32_t used = (uint32_t)old, chunk = (uint32_t)(old >> 32);
-            if (used + n <= CHUNK) { pos0 = (unsigned long long)chunk * CHUNK + used; n0 = n; break; }
-            if (used <= CHUNK) {  // this allocation crosses the end: it alone refills
-                n0 = CHUNK - used;
-                pos0 = (unsigned long long)chunk * CHUNK + used;
-                const unsigned long long nc = atomicAdd(g_head, 1ull);
-                pos1 = nc * CHUNK;
+    for (;;) {
+        unsigned long long old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&state, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = wave_first_u64(old);
+        const uint32_t used = (uint32_t)old, chunk = (uint32_t)(old >> 32);
+        if (used + n <= CHUNK) return Slots{(unsigned long long)chunk * CHUNK + used, 0ull, n};
+        if (used <= CHUNK) {  // this allocation crosses the end: it alone refills
+            const uint32_t n0 = CHUNK - used;
+            unsigned long long nc = 0;
+            if (lane == 0) {
+                nc = atomicAdd(g_head, 1ull);
                 __hip_atomic_store(&state, (nc << 32) | (unsigned long long)(n - n0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
             }
-            while ((uint32_t)(__hip_atomic_load(&state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == chunk)
-                __builtin_amdgcn_s_sleep(2);
+            nc = wave_first_u64(nc);
+            return Slots{(unsigned long long)chunk * CHUNK + used, nc * CHUNK, n0};
         }
+        // exhausted while another wave refills: sleep on the LDS word until the new chunk is published, then retry
+        while ((uint32_t)(wave_first_u64(__hip_atomic_load(&state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) == chunk)
+            __builtin_amdgcn_s_sleep(2);
     }
-    Slots sl;
-    sl.pos0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(pos0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pos0);
-    sl.pos1 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(pos1 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pos1);
-    sl.n0 = __builtin_amdgcn_readfirstlane(n0);
-    return sl;
 }
 
 // Phase 2 on up to 64 survivors.  Returns the number of valid candidate pairs of the batch.  PROBES == false keeps the
