@@ -171,6 +171,35 @@ DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *h
     return clash ? (1u << ARP_StericClash) : kind;                                              // complex.rs:233-235
 }
 
+// The same rules for the hot kernel (no probes): pair predicates as bits of a few integer words instead of one boolean per
+// rule -- the boolean form compiled to ~100 vector instructions per batch (0/1 materialisations and selects), this one to
+// about half.  A pair is handed to the deferred pass (which runs classify<true>, exact for every pair) when a probe MAY be
+// needed: a donor/acceptor pair within 4.0 A where either residue carries hydrogens (a superset of hbond.rs:37-42,81-86:
+// the reference only looks at the donor's residue), or a CYS SG..SG pair in the covalent band (vdw.rs:46-53).
+// Attribute bits: DONOR 4, ACCEPTOR 5, WEAK_DONOR 6, POS 7, NEG 8, HYDROPHOBIC 9, CYS_SG 10, residue-has-H 31.
+DEVFN uint32_t classify_fast(const LdsParams &prm, double s, uint32_t A, uint32_t B, uint32_t have_res) {
+    const uint32_t e = ((A & ARP_ATTR_ELEM_MASK) << 4) | (B & ARP_ATTR_ELEM_MASK);
+    const bool clash = s < prm.s_clash[e], cov = s < prm.s_cov[e], vdw = s < prm.s_vdw[e];  // vdw.rs:32-43 (strict <)
+    const uint32_t near4 = s < prm.s_ion ? 1u : 0u, near35 = s < prm.s_polar ? 1u : 0u, near45 = s < prm.s_hphob ? 1u : 0u;
+    const uint32_t A1 = A >> 1, B1 = B >> 1;
+    const uint32_t x = (A & B1) | (B & A1);      // bit 4: donor..acceptor either way (hbond.rs:113-134), bit 7: POS..NEG either way
+    const uint32_t y = (A1 & B) | (B1 & A);      // bit 5: weak donor (6 -> 5)..acceptor either way (hbond.rs:181-201)
+    const uint32_t both = A & B;                 // bit 7 / 8: POS..POS / NEG..NEG, bit 9: hydrophobic pair, bit 10: CYS SG pair
+    const uint32_t strong = (x >> 4) & 1u, weak = (y >> 5) & 1u, ion = (x >> 7) & 1u;
+    const uint32_t rep = ((both | (both >> 1)) >> 7) & 1u, hy = (both >> 9) & 1u, sg = (both >> 10) & 1u;
+    const uint32_t any_h = (A | B) >> 31;
+    const uint32_t probe = (near4 & (strong | weak) & any_h) | ((cov ? 1u : 0u) & sg & have_res);
+    const uint32_t ionic = near4 & ion;                                                          // ionic.rs:11-22,37-57
+    uint32_t kind = cov ? (1u << ARP_CovalentBond) : (vdw ? (1u << ARP_VanDerWaalsContact) : 0u);
+    kind |= ionic << ARP_IonicBond;
+    kind |= (strong & near35 & ~ionic) << ARP_PolarContact;                                      // complex.rs:240-251 without a probe
+    kind |= (weak & near35) << ARP_WeakPolarContact;
+    kind |= (near4 & rep) << ARP_IonicRepulsion;                                                 // ionic.rs:25-35,59-81
+    kind |= (near45 & hy) << ARP_HydrophobicContact;                                             // hydrophobic.rs:10-24
+    kind = probe ? kDeferKind : kind;
+    return clash ? (1u << ARP_StericClash) : kind;                                               // complex.rs:233-235
+}
+
 // (float) of the correctly rounded f64 square root -- what the reference stores in the table (mod.rs:148) -- without the
 // library sqrt on the common path.  f32 rsq seed r (relative error e0 <= 2^-22.4), one coupled Newton step in f64
 // (y1 = sqrt(s)(1 - e0^2), h1 = (1 - e0^2) / (2 sqrt(s))) and the residual correction y2 = y1 + (s - y1^2) h1, whose error

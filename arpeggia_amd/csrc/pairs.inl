@@ -130,7 +130,8 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
 #if defined(ARP_ABLATE) && ARP_ABLATE == 13   // timing ablation: no classification
             r.w = (a.attr ^ b.attr) & 1u;
 #else
-            r.w = classify<PROBES>(in, prm, so.hinfo, s, a, ent.x, b, ent.y, swap, result);
+            if (PROBES) r.w = classify<true>(in, prm, so.hinfo, s, a, ent.x, b, ent.y, swap, result);
+            else r.w = classify_fast(prm, s, a.attr, b.attr, in.n_res != 0u ? 1u : 0u);
 #endif
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
 #if defined(ARP_ABLATE) && ARP_ABLATE == 14   // timing ablation: no output distance
