@@ -89,15 +89,22 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # ARP_BENCH_REHEARSE=1: all ranks share cuda:0 and rendezvous over gloo -- exercises this multi-process path on a one-GPU box
+    # (the driver's real N > 1 runs use one GPU per rank over RCCL)
+    rehearse = os.environ.get("ARP_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     # ---- synthetic structure of this rank (independent structures shard with no exchange) ----
     seed = 0xA11CE5EED00 + 4 + 1000 * rank
@@ -110,7 +117,7 @@ def main():
     atoms = aa.atoms_from_arrays(dsoa, location=_lib.ARP_MEM_DEVICE, keep=keep)
     prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only)
     stream = torch.cuda.current_stream(dev)
-    ctx = aa.Context(local_rank, stream=stream.cuda_stream)
+    ctx = aa.Context(dev_index, stream=stream.cuda_stream)
 
     # size the output once (count pass), then everything is allocation-free
     n_pairs = ctx.count(atoms, prm)
@@ -153,7 +160,7 @@ def main():
             acc[k] = acc.get(k, 0.0) + v / args.profile_steps
     ctx.profile(False)
 
-    wall_max, pairs_all = reduce_job(dist, dev, wall, n_pairs)  # max over ranks / sum over ranks; no data-path collective
+    wall_max, pairs_all = reduce_job(dist, "cpu" if rehearse else dev, wall, n_pairs)  # max over ranks / sum over ranks; no data-path collective
 
     if rank == 0:
         # HBM traffic of the dominant kernel cannot be counted from inside this process; when the run matches the configuration
