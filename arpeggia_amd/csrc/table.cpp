@@ -106,17 +106,47 @@ struct PlaneEntry {
     bool has_ord = false; uint32_t ord = 0;   // res2idx[(model, chain, resi, icode, altloc, resn)]
     uint16_t chain_rank = 0; bool in_l = false, in_r = false;
 };
-using PlaneKey = std::tuple<int32_t, std::string, int32_t, std::string, std::string, std::string>;
+// (model serial, chain id, resi, icode, altloc, resn) with the names packed into integers (ids are <= 7 / 3 characters, the
+// widths of the string columns): hashing and comparing keys costs no allocation.
+struct PlaneKey {
+    int32_t model, resi;
+    uint32_t icode, altloc;
+    uint64_t chain, resn;
+    bool operator==(const PlaneKey &o) const {
+        return model == o.model && resi == o.resi && icode == o.icode && altloc == o.altloc && chain == o.chain && resn == o.resn;
+    }
+};
+struct PlaneKeyHash {
+    size_t operator()(const PlaneKey &k) const {
+        uint64_t h = k.chain * 0x9E3779B97F4A7C15ull ^ k.resn;
+        h = (h ^ (h >> 29)) * 0xBF58476D1CE4E5B9ull + (((uint64_t)(uint32_t)k.model << 32) | (uint32_t)k.resi);
+        h = (h ^ (h >> 31)) * 0x94D049BB133111EBull + (((uint64_t)k.icode << 32) | k.altloc);
+        return (size_t)(h ^ (h >> 32));
+    }
+};
+using PlaneIndex = std::unordered_map<PlaneKey, size_t, PlaneKeyHash>;
+static uint64_t pack_name(const char *s, size_t cap) {  // up to `cap` bytes, NUL padded
+    uint64_t v = 0;
+    size_t n = 0;
+    while (n < cap && s[n]) n++;
+    memcpy(&v, s, n);
+    return v;
+}
+static PlaneKey plane_key(int32_t model, const char *chain, int32_t resi, const char *icode, const char *altloc, const char *resn) {
+    return PlaneKey{model, resi, (uint32_t)pack_name(icode, 4), (uint32_t)pack_name(altloc, 4), pack_name(chain, 8), pack_name(resn, 8)};
+}
 
-static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEntry> *out, std::map<PlaneKey, size_t> *index) {
+static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEntry> *out, PlaneIndex *index) {
     std::vector<int32_t> serials;
     for (const ChainInfo &c : s.chains) if (std::find(serials.begin(), serials.end(), c.model_serial) == serials.end()) serials.push_back(c.model_serial);
     // res2idx: (model serial, chain, resi, icode) -> residue
-    std::map<std::tuple<int32_t, std::string, int32_t, std::string>, uint32_t> res_of;
+    std::unordered_map<PlaneKey, uint32_t, PlaneKeyHash> res_of;
+    res_of.reserve(s.residues.size() * 2);
     for (uint32_t r = 0; r < s.residues.size(); r++) {
         const ResidueInfo &ri = s.residues[r];
-        res_of[{s.chains[ri.chain].model_serial, s.chains[ri.chain].id, ri.resi, ri.icode}] = r;
+        res_of[plane_key(s.chains[ri.chain].model_serial, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), "", "")] = r;
     }
+    index->reserve(s.residues.size() * 2);
     // complex.rs:447-449 / 489-492: for EVERY model serial, ALL chains of ALL models are visited; later inserts overwrite
     for (int32_t m : serials)
         for (uint32_t r = 0; r < s.residues.size(); r++) {
@@ -129,7 +159,7 @@ static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEn
             Plane pl;
             if (!fit_plane(pts, &pl)) continue;  // complex.rs:471-474 warning path / :506 None
             for (const std::string &alt : ri.altlocs) {
-                PlaneKey key{m, s.chains[ri.chain].id, ri.resi, ri.icode, alt, ri.name};
+                const PlaneKey key = plane_key(m, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), alt.c_str(), ri.name.c_str());
                 auto it = index->find(key);
                 if (it == index->end()) { it = index->emplace(key, out->size()).first; out->push_back(PlaneEntry{}); }
                 PlaneEntry &e = (*out)[it->second];
@@ -138,7 +168,7 @@ static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEn
             }
         }
     for (PlaneEntry &e : *out) {
-        auto it = res_of.find({e.model_serial, e.chain, e.resi, e.icode});
+        auto it = res_of.find(plane_key(e.model_serial, e.chain.c_str(), e.resi, e.icode.c_str(), "", ""));
         if (it == res_of.end()) continue;
         const ResidueInfo &ri = s.residues[it->second];
         if (ri.name != e.resn || std::find(ri.altlocs.begin(), ri.altlocs.end(), e.altloc) == ri.altlocs.end()) continue;
@@ -204,7 +234,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     arp_status st = arp_structure_atoms(s, groups, &view);
     if (st != ARP_OK) return st;
     std::vector<PlaneEntry> rings, scp;
-    std::map<PlaneKey, size_t> ring_idx, sc_idx;
+    PlaneIndex ring_idx, sc_idx;
     build_planes(*s, true, &rings, &ring_idx);
     if (rings.empty()) { set_error("Error building ring positions"); return ARP_ERR_NO_RINGS; }  // complex.rs:50
     build_planes(*s, false, &scp, &sc_idx);
@@ -242,7 +272,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
             const uint64_t key = ((uint64_t)s->res_id[a] << 32) | alt;
             auto it = memo.find(key);
             if (it == memo.end()) {
-                auto f = sc_idx.find(PlaneKey{s->model_serial[a], s->chain.str(a), s->resi[a], s->icode.str(a), s->altloc.str(a), s->res_resn.str(a)});
+                auto f = sc_idx.find(plane_key(s->model_serial[a], s->chain.at(a), s->resi[a], s->icode.at(a), s->altloc.at(a), s->res_resn.at(a)));
                 it = memo.emplace(key, f == sc_idx.end() ? -1 : (int64_t)f->second).first;
             }
             atom_sc[a] = it->second;
@@ -261,7 +291,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
         put(e.chain, 8, r.chain); put(e.resn, 8, r.resn); put(e.atomn, 8, "Ring"); put(e.insertion, 4, r.icode); put(e.altloc, 4, r.altloc);
         e.resi = r.resi; e.atomi = 0; e.atom = -1;
         e.chain_rank = r.chain_rank;
-        auto f = sc_idx.find(PlaneKey{r.model_serial, r.chain, r.resi, r.icode, r.altloc, r.resn});
+        auto f = sc_idx.find(plane_key(r.model_serial, r.chain.c_str(), r.resi, r.icode.c_str(), r.altloc.c_str(), r.resn.c_str()));
         e.sc_plane = f == sc_idx.end() ? -1 : (int64_t)f->second;
         return e;
     };
@@ -324,26 +354,39 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
         std::sort(o.begin(), o.end(), [](int a, int b) { return strcmp(arp_interaction_name(a), arp_interaction_name(b)) < 0; });
         for (int k = 0; k < ARP_N_INTERACTIONS; k++) name_rank[o[k]] = k;
     }
-    std::vector<uint32_t> order(rows.size());
-    for (size_t k = 0; k < rows.size(); k++) order[k] = (uint32_t)k;
-    std::sort(order.begin(), order.end(), [&](uint32_t ia, uint32_t ib) {
-        const Row &a = rows[ia], &b = rows[ib];
+    // Sort keys as plain integers, compared in place (no indirection into the rows): names as big-endian words, so that an
+    // unsigned compare is the byte-wise string order polars uses.
+    struct SortKey {
+        uint32_t model; uint16_t from_chain, to_chain;
+        int32_t from_resi; uint32_t from_altloc; int32_t from_atomi, to_resi; uint32_t to_altloc; int32_t to_atomi, interaction;
+        uint32_t from_ins, to_ins; double distance; uint32_t idx;
+    };
+    auto be32 = [](const char *p) { return ((uint32_t)(unsigned char)p[0] << 24) | ((uint32_t)(unsigned char)p[1] << 16) | ((uint32_t)(unsigned char)p[2] << 8) | (uint32_t)(unsigned char)p[3]; };
+    std::vector<SortKey> keys(rows.size());
+    for (size_t k = 0; k < rows.size(); k++) {
+        const Row &r = rows[k];
+        keys[k] = SortKey{r.model, r.from.chain_rank, r.to.chain_rank, r.from.resi, be32(r.from.altloc), r.from.atomi, r.to.resi, be32(r.to.altloc),
+                          r.to.atomi, name_rank[r.interaction], be32(r.from.insertion), be32(r.to.insertion), r.distance, (uint32_t)k};
+    }
+    std::sort(keys.begin(), keys.end(), [](const SortKey &a, const SortKey &b) {
         if (a.model != b.model) return a.model < b.model;
-        if (a.from.chain_rank != b.from.chain_rank) return a.from.chain_rank < b.from.chain_rank;
-        if (a.to.chain_rank != b.to.chain_rank) return a.to.chain_rank < b.to.chain_rank;
-        if (a.from.resi != b.from.resi) return a.from.resi < b.from.resi;
-        if (int c = strcmp(a.from.altloc, b.from.altloc)) return c < 0;
-        if (a.from.atomi != b.from.atomi) return a.from.atomi < b.from.atomi;
-        if (a.to.resi != b.to.resi) return a.to.resi < b.to.resi;
-        if (int c = strcmp(a.to.altloc, b.to.altloc)) return c < 0;
-        if (a.to.atomi != b.to.atomi) return a.to.atomi < b.to.atomi;
-        if (a.interaction != b.interaction) return name_rank[a.interaction] < name_rank[b.interaction];
+        if (a.from_chain != b.from_chain) return a.from_chain < b.from_chain;
+        if (a.to_chain != b.to_chain) return a.to_chain < b.to_chain;
+        if (a.from_resi != b.from_resi) return a.from_resi < b.from_resi;
+        if (a.from_altloc != b.from_altloc) return a.from_altloc < b.from_altloc;
+        if (a.from_atomi != b.from_atomi) return a.from_atomi < b.from_atomi;
+        if (a.to_resi != b.to_resi) return a.to_resi < b.to_resi;
+        if (a.to_altloc != b.to_altloc) return a.to_altloc < b.to_altloc;
+        if (a.to_atomi != b.to_atomi) return a.to_atomi < b.to_atomi;
+        if (a.interaction != b.interaction) return a.interaction < b.interaction;
         // the reference's sort is unstable on full ties; break them deterministically
-        if (int c = strcmp(a.from.insertion, b.from.insertion)) return c < 0;
-        if (int c = strcmp(a.to.insertion, b.to.insertion)) return c < 0;
+        if (a.from_ins != b.from_ins) return a.from_ins < b.from_ins;
+        if (a.to_ins != b.to_ins) return a.to_ins < b.to_ins;
         if (a.distance != b.distance) return a.distance < b.distance;
-        return ia < ib;
+        return a.idx < b.idx;
     });
+    std::vector<uint32_t> order(rows.size());
+    for (size_t k = 0; k < rows.size(); k++) order[k] = keys[k].idx;
     lap("sort");
     arp_table *t = new arp_table();
     const size_t n = rows.size();
@@ -352,6 +395,8 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     t->from_atom.resize(n); t->to_atom.resize(n); t->distance.resize(n); t->sc_dist.resize(n); t->sc_dihedral.resize(n); t->sc_angle.resize(n); t->sc_valid.resize(n);
     t->from_chain.resize(n); t->from_resn.resize(n); t->from_atomn.resize(n); t->to_chain.resize(n); t->to_resn.resize(n); t->to_atomn.resize(n);
     t->from_insertion.resize(n); t->from_altloc.resize(n); t->to_insertion.resize(n); t->to_altloc.resize(n);
+    uint64_t last_pair = ~0ull;
+    float last_sc[3] = {0.f, 0.f, 0.f};
     for (size_t k = 0; k < n; k++) {
         const Row &r = rows[order[k]];
         t->model[k] = r.model; t->interaction[k] = r.interaction; t->distance[k] = (float)r.distance;  // mod.rs:148
@@ -362,12 +407,15 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
         t->to_insertion.set(k, r.to.insertion); t->to_altloc.set(k, r.to.altloc);
         t->to_resi[k] = r.to.resi; t->to_atomi[k] = r.to.atomi; t->to_atom[k] = r.to.atom;
         // collect_sc_stats (complex.rs:137-174): res1 = ligand residue, res2 = receptor residue
-        if (r.from.sc_plane >= 0 && r.to.sc_plane >= 0) {
-            const Plane &p1 = scp[r.from.sc_plane].plane, &p2 = scp[r.to.sc_plane].plane;
+        if (r.from.sc_plane >= 0 && r.to.sc_plane >= 0) {  // rows are sorted by residue pair: consecutive rows mostly share the planes
+            const uint64_t pk = ((uint64_t)r.from.sc_plane << 32) | (uint64_t)r.to.sc_plane;
+            if (pk != last_pair) {
+                const Plane &p1 = scp[r.from.sc_plane].plane, &p2 = scp[r.to.sc_plane].plane;
+                last_sc[0] = (float)point_dist(p1, p2.c); last_sc[1] = (float)plane_dihedral(p1, p2); last_sc[2] = (float)point_angle(p1, p2.c);
+                last_pair = pk;
+            }
             t->sc_valid[k] = 1;
-            t->sc_dist[k] = (float)point_dist(p1, p2.c);
-            t->sc_dihedral[k] = (float)plane_dihedral(p1, p2);
-            t->sc_angle[k] = (float)point_angle(p1, p2.c);
+            t->sc_dist[k] = last_sc[0]; t->sc_dihedral[k] = last_sc[1]; t->sc_angle[k] = last_sc[2];
         }
     }
     lap("columns + sc stats");
