@@ -54,14 +54,13 @@ struct DevAtoms {
 struct __attribute__((aligned(16))) Fat {
     double x, y, z;
     uint32_t attr, res_ord, crm /* chain_rank | model << 16 */, orig /* index into the caller's arrays */;
+    uint32_t cell, spare;  // cell id of the slot (a task's home lanes derive their windows from it); fills the 16-byte tail
 };
 
 // Cell-sorted copy of the heavy atoms (slot order: x-major cells, atoms of a cell in ascending input index).
 struct Sorted {
     float4 *rec;          // {x-mx, y-my, z-mz as f32, |.|^2 of those three}  -- prefilter operand, 16 B
-    uint32_t *cell;       // cell id of the slot (the home side of a task derives its windows from it)
     Fat *fat;
-    uint2 *hinfo;         // [begin, end) of the residue's hydrogens in res_h_idx
 };
 
 // Same-address (and same-line) device atomics serialise in one L2 channel at ~90 ns each: the task counters of the eight XCD

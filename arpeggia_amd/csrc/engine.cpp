@@ -135,7 +135,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.partials, 1024 * 8); A(w.tickets, 4); A(w.grid, 1); A(w.params, 1);
     A(w.cell_of_atom, cap); A(w.rank_of_atom, cap); A(w.cell_count, ccap + 1); A(w.cell_start, ccap + 1);
     A(w.perm, cap); A(w.slot_cell, cap);
-    A(w.sorted.rec, cap + 64); A(w.sorted.cell, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.hinfo, cap);
+    A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);

@@ -245,7 +245,14 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
     const uint32_t n = *n_ptr;
     const uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
     const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
-    TOut carry = tmp[blockIdx.x];
+    // carry = sum of the partial totals of the blocks before this one, recomputed here from the kScanBlocks raw totals
+    // (4-8 KB out of L2): one launch less than scanning them in a kernel of their own
+    TOut part = 0, all = 0;
+    for (uint32_t k = threadIdx.x; k < kScanBlocks; k += kScanThreads) { const TOut v = tmp[k]; all += v; if (k < blockIdx.x) part += v; }
+    TOut carry, grand = 0;
+    block_exclusive_scan<TOut>(part, &carry, lds);
+    __syncthreads();
+    if (blockIdx.x == 0) { block_exclusive_scan<TOut>(all, &grand, lds); __syncthreads(); }
     for (uint32_t base = lo; base < hi; base += kScanThreads) {
         const uint32_t i = base + threadIdx.x;
         TOut v = (i < hi) ? (TOut)in[i] : (TOut)0, tot;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
         __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const TOut total = tmp[kScanBlocks];
+        const TOut total = grand;
         out[n] = total;
         if (FINISH) {  // the pair-count scan also publishes the result word and the status flags
             result[0] = (unsigned long long)total;
@@ -272,19 +279,16 @@ DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so
     const double x = in.x[i], y = in.y[i], z = in.z[i];
     const float fx = (float)(x - gp->mx), fy = (float)(y - gp->my), fz = (float)(z - gp->mz);
     so.rec[d] = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
-    so.cell[d] = c;
     Fat f;
     f.x = x; f.y = y; f.z = z;
     f.attr = in.attr[i] & ~kAttrResHasH; f.res_ord = in.res_ord[i]; f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i;
-    // Resolve the residue -> hydrogens indirection once per atom: the pair kernel touches the hydrogen tables only for
-    // donors whose residue really carries hydrogens (hbond.rs:38-42), with no dependent loads on the common path.
-    uint2 hi = make_uint2(0u, 0u);
+    f.cell = c; f.spare = 0u;
+    // "the residue carries hydrogens" as an attribute bit: the hot kernel never touches the hydrogen tables, the deferred
+    // pass resolves residue -> hydrogens itself (hbond.rs:38-42)
     if (in.n_res) {
         const uint32_t r = in.res_id[i];
-        hi.x = in.res_h_ptr[r]; hi.y = in.res_h_ptr[r + 1];
-        if (hi.x < hi.y) f.attr |= kAttrResHasH;
+        if (in.res_h_ptr[r] < in.res_h_ptr[r + 1]) f.attr |= kAttrResHasH;
     }
-    so.hinfo[d] = hi;
     so.fat[d] = f;
 }
 

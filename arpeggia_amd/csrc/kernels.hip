@@ -121,9 +121,9 @@ constexpr uint32_t kDeferKind = 0xFFFFFFFFu;  // classify<false>: the pair needs
 
 // (weak) hydrogen bond test of hbond.rs:36-58 / 80-102 for the donor chosen by `donor_is_a`: true iff some hydrogen of the donor's
 // residue satisfies the distance and angle conditions.  Only called for donors whose residue carries hydrogens.
-DEVFN bool hbond_probe(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, bool donor_is_a, const Fat &a, uint32_t sa, const Fat &b,
-                       uint32_t sb, double min_angle) {
-    const uint2 hi = hinfo[donor_is_a ? sa : sb];
+DEVFN bool hbond_probe(const DevAtoms &in, const LdsParams &prm, bool donor_is_a, const Fat &a, const Fat &b, double min_angle) {
+    const uint32_t res = in.res_id[donor_is_a ? a.orig : b.orig];
+    const uint2 hi = make_uint2(in.res_h_ptr[res], in.res_h_ptr[res + 1]);
     const uint32_t acc_attr = donor_is_a ? b.attr : a.attr;
     const double dx = donor_is_a ? a.x : b.x, dy = donor_is_a ? a.y : b.y, dz = donor_is_a ? a.z : b.z;
     const double ax = donor_is_a ? b.x : a.x, ay = donor_is_a ? b.y : a.y, az = donor_is_a ? b.z : a.z;
@@ -135,8 +135,7 @@ DEVFN bool hbond_probe(const DevAtoms &in, const LdsParams &prm, const uint2 *hi
 // argument order of the disulfide dihedral; `swap` says that b is the ligand.  Everything on the common path is
 // straight-line predicate arithmetic; only the rare probes branch (PROBES) or defer the pair (!PROBES).
 template <bool PROBES>
-DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *hinfo, double s, const Fat &a, uint32_t sa, const Fat &b,
-                        uint32_t sb, bool swap, unsigned long long *result) {
+DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, double s, const Fat &a, const Fat &b, bool swap, unsigned long long *result) {
     const uint32_t aa = a.attr, ab = b.attr, both = aa & ab;
     const uint32_t e = ((aa & ARP_ATTR_ELEM_MASK) << 4) | (ab & ARP_ATTR_ELEM_MASK);  // the radius tables are symmetric
     const double t_clash = prm.s_clash[e], t_cov = prm.s_cov[e], t_vdw = prm.s_vdw[e];
@@ -154,8 +153,8 @@ DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, const uint2 *h
     if (!clash && (need_hs | need_hw | need_ss)) {                                     // rare
         if (!PROBES) return kDeferKind;
         if (need_ss) ss = disulfide_probe(in.x, in.y, in.z, in.res_id, in.res_cb, in.res_sg, swap ? b.orig : a.orig, swap ? a.orig : b.orig, result);
-        if (need_hs) hb2 = hbond_probe(in, prm, hinfo, sd_a, a, sa, b, sb, 90.0);
-        if (need_hw) wk2 = hbond_probe(in, prm, hinfo, wd_a, a, sa, b, sb, 130.0);
+        if (need_hs) hb2 = hbond_probe(in, prm, sd_a, a, b, 90.0);
+        if (need_hw) wk2 = hbond_probe(in, prm, wd_a, a, b, 130.0);
     }
     const bool ionic = near4 & ((((aa >> 7) & (ab >> 8)) | ((ab >> 7) & (aa >> 8))) & 1u);     // ionic.rs:11-22,37-57
     const bool repel = near4 & (((both >> 7) | (both >> 8)) & 1u);                              // ionic.rs:25-35,59-81

@@ -130,7 +130,7 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
 #if defined(ARP_ABLATE) && ARP_ABLATE == 13   // timing ablation: no classification
             r.w = (a.attr ^ b.attr) & 1u;
 #else
-            if (PROBES) r.w = classify<true>(in, prm, so.hinfo, s, a, ent.x, b, ent.y, swap, result);
+            if (PROBES) r.w = classify<true>(in, prm, s, a, b, swap, result);
             else r.w = classify_fast(prm, s, a.attr, b.attr, in.n_res != 0u ? 1u : 0u);
 #endif
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
         uint32_t cx = 0, cy = 0, cz = 0;
         if (have) {
             home = so.rec[a];
-            uint32_t c = so.cell[a];
+            uint32_t c = so.fat[a].cell;
             cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
         }
         const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
@@ -505,7 +505,6 @@ static void launch_scan(uint32_t *in, const uint32_t *n_ptr, TOut *tmp, TOut *ou
                         bool have_out, hipStream_t st) {
     (void)ticket;
     hipLaunchKernelGGL(k_scan_reduce<TOut>, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const uint32_t *)in, n_ptr, tmp);
-    hipLaunchKernelGGL(k_scan_tmp<TOut>, dim3(1), dim3(kScanThreads), 0, st, tmp);
     hipLaunchKernelGGL((k_scan_apply<TOut, ZERO_IN, FINISH>), dim3(kScanBlocks), dim3(kScanThreads), 0, st, in, n_ptr, (const TOut *)tmp, out,
                        (const GridParams *)ws.grid, ws.result, capacity, have_out ? 1 : 0);
 }
