@@ -95,10 +95,22 @@ __device__ __noinline__ int hydrogen_probe(const double *X, const double *Y, con
                                            uint32_t p0, uint32_t p1, double dx, double dy, double dz, double ax, double ay, double az,
                                            double min_angle) {
     const double pd[3] = {dx, dy, dz}, pa[3] = {ax, ay, az};
-    for (uint32_t p = p0; p < p1; p++) {
-        const uint32_t h = res_h_idx[p];
-        const double ph[3] = {X[h], Y[h], Z[h]};
-        if (sq_dist(ph[0], ph[1], ph[2], pa[0], pa[1], pa[2]) < lim && angle_deg(pd, ph, pa) >= min_angle) return 1;
+    // four hydrogens per trip: index loads, then twelve coordinate loads in flight together -- one by one the loop is a chain
+    // of dependent round trips (index -> coordinates) per hydrogen.  "Some hydrogen qualifies" does not depend on the order.
+    for (uint32_t p = p0; p < p1; p += 4u) {
+        uint32_t h[4];
+        double hx[4], hy[4], hz[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) h[u] = res_h_idx[min(p + u, p1 - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) { hx[u] = X[h[u]]; hy[u] = Y[h[u]]; hz[u] = Z[h[u]]; }
+        bool hit = false;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const double ph[3] = {hx[u], hy[u], hz[u]};
+            if (p + u < p1 && sq_dist(ph[0], ph[1], ph[2], pa[0], pa[1], pa[2]) < lim) hit = hit || (angle_deg(pd, ph, pa) >= min_angle);
+        }
+        if (hit) return 1;
     }
     return 0;
 }
