@@ -306,44 +306,77 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     arp_pairs_free(&pairs);
     lap("atom rows");
 
-    // get_ring_atom_contacts (complex.rs:301-352) + find_cation_pi (aromatic.rs:14-29)
+    // Ring centroids in a hash grid (cell edge = the larger of the two search radii): the reference walks an R*-tree for the
+    // ring-atom rows and ALL ring pairs for the ring-ring rows (complex.rs:354-405, O(R^2)); both become linear here.
     const double r2 = dist_cutoff * dist_cutoff;
+    const double cell_edge = std::max(std::max(dist_cutoff, 6.0), 1e-3);
+    auto cell_of = [&](const double q[3], int64_t c[3]) { for (int k = 0; k < 3; k++) c[k] = (int64_t)std::floor(q[k] / cell_edge); };
+    auto cell_key = [](int32_t model, const int64_t c[3]) {
+        uint64_t h = (uint64_t)(uint32_t)model * 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < 3; k++) h = (h ^ (uint64_t)c[k]) * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+        return h ^ (h >> 31);
+    };
+    std::unordered_map<uint64_t, std::vector<uint32_t>> ring_cells;  // key collisions only add candidates: every hit is distance-tested
+    bool rings_finite = true;
+    for (uint32_t k = 0; k < rings.size(); k++) {
+        const PlaneEntry &ring = rings[k];
+        if (!ring.has_ord) continue;
+        if (!(std::isfinite(ring.plane.c[0]) && std::isfinite(ring.plane.c[1]) && std::isfinite(ring.plane.c[2]))) { rings_finite = false; continue; }
+        int64_t c[3];
+        cell_of(ring.plane.c, c);
+        ring_cells[cell_key(ring.model_serial, c)].push_back(k);
+    }
+    (void)rings_finite;
+    auto for_rings_near = [&](int32_t model, const double q[3], auto &&fn) {
+        if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) return;
+        int64_t c[3], d[3];
+        cell_of(q, c);
+        for (d[0] = c[0] - 1; d[0] <= c[0] + 1; d[0]++)
+            for (d[1] = c[1] - 1; d[1] <= c[1] + 1; d[1]++)
+                for (d[2] = c[2] - 1; d[2] <= c[2] + 1; d[2]++) {
+                    auto it = ring_cells.find(cell_key(model, d));
+                    if (it == ring_cells.end()) continue;
+                    for (uint32_t k : it->second) fn(k);
+                }
+    };
+    // get_ring_atom_contacts (complex.rs:301-352) + find_cation_pi (aromatic.rs:14-29)
     {
-        // atoms that can ever produce a row are the few positively ionizable ones: index only those
-        std::vector<uint32_t> pos;
-        for (size_t a = 0; a < s->n; a++) if (s->attr[a] & ARP_ATTR_POS_RESN) pos.push_back((uint32_t)a);
-        for (const PlaneEntry &ring : rings) {
-            if (!ring.has_ord) continue;
-            ResKey rk{ring.model_serial, ring.chain_rank, ring.ord, ring.in_l, ring.in_r};
-            for (uint32_t a : pos) {
-                double q[3] = {s->x[a], s->y[a], s->z[a]};
-                double dx = q[0] - ring.plane.c[0], dy = q[1] - ring.plane.c[1], dz = q[2] - ring.plane.c[2];
-                if (!(dx * dx + dy * dy + dz * dz <= r2)) continue;
-                ResKey yk{s->model_serial[a], s->chain_rank[a], s->res_ord[a], (s->attr[a] & ARP_ATTR_LIGAND) != 0, (s->attr[a] & ARP_ATTR_RECEPTOR) != 0};
-                if (!compare_residues(rk, yk, false)) continue;
-                double dist = point_dist(ring.plane, q), theta = point_angle(ring.plane, q);
-                if (theta <= 30.0 && dist <= 4.5) rows.push_back(Row{(uint32_t)ring.model_serial, ARP_CationPi, dist, entity_from_ring(ring), entity_from_atom(a)});
-            }
+        // atoms that can ever produce a row are the few positively ionizable ones
+        for (size_t a = 0; a < s->n; a++) {
+            if (!(s->attr[a] & ARP_ATTR_POS_RESN)) continue;
+            const double q[3] = {s->x[a], s->y[a], s->z[a]};
+            const ResKey yk{s->model_serial[a], s->chain_rank[a], s->res_ord[a], (s->attr[a] & ARP_ATTR_LIGAND) != 0, (s->attr[a] & ARP_ATTR_RECEPTOR) != 0};
+            for_rings_near(s->model_serial[a], q, [&](uint32_t k) {
+                const PlaneEntry &ring = rings[k];
+                if (ring.model_serial != s->model_serial[a]) return;
+                const double dx = q[0] - ring.plane.c[0], dy = q[1] - ring.plane.c[1], dz = q[2] - ring.plane.c[2];
+                if (!(dx * dx + dy * dy + dz * dz <= r2)) return;
+                const ResKey rk{ring.model_serial, ring.chain_rank, ring.ord, ring.in_l, ring.in_r};
+                if (!compare_residues(rk, yk, false)) return;
+                const double dist = point_dist(ring.plane, q), theta = point_angle(ring.plane, q);
+                if (theta <= 30.0 && dist <= 4.5) rows.push_back(Row{(uint32_t)ring.model_serial, ARP_CationPi, dist, entity_from_ring(ring), entity_from_atom((uint32_t)a)});
+            });
         }
     }
     // get_ring_ring_contacts (complex.rs:354-405) + find_pi_pi (aromatic.rs:33-64)
     for (const PlaneEntry &k1 : rings) {
         if (!k1.has_ord || !k1.in_l) continue;
-        ResKey r1{k1.model_serial, k1.chain_rank, k1.ord, k1.in_l, k1.in_r};
-        for (const PlaneEntry &k2 : rings) {
-            if (!k2.has_ord || !k2.in_r) continue;
-            double v[3] = {k1.plane.c[0] - k2.plane.c[0], k1.plane.c[1] - k2.plane.c[1], k1.plane.c[2] - k2.plane.c[2]};
-            double dist = norm3(v);
-            if (!(dist <= 6.0)) continue;
-            ResKey r2k{k2.model_serial, k2.chain_rank, k2.ord, k2.in_l, k2.in_r};
-            if (!compare_residues(r1, r2k, true)) continue;
-            double theta = point_angle(k1.plane, k2.plane.c), dih = plane_dihedral(k1.plane, k2.plane);
+        const ResKey r1{k1.model_serial, k1.chain_rank, k1.ord, k1.in_l, k1.in_r};
+        for_rings_near(k1.model_serial, k1.plane.c, [&](uint32_t kk) {
+            const PlaneEntry &k2 = rings[kk];
+            if (!k2.in_r || k2.model_serial != k1.model_serial) return;
+            const double v[3] = {k1.plane.c[0] - k2.plane.c[0], k1.plane.c[1] - k2.plane.c[1], k1.plane.c[2] - k2.plane.c[2]};
+            const double dist = norm3(v);
+            if (!(dist <= 6.0)) return;
+            const ResKey r2k{k2.model_serial, k2.chain_rank, k2.ord, k2.in_l, k2.in_r};
+            if (!compare_residues(r1, r2k, true)) return;
+            const double theta = point_angle(k1.plane, k2.plane.c), dih = plane_dihedral(k1.plane, k2.plane);
             int code = -1;
             if (dih <= 30.0) { if (theta <= 30.0) code = ARP_PiSandwichStacking; else if (theta <= 60.0) code = ARP_PiDisplacedStacking; else if (theta <= 90.0) code = ARP_PiParallelInPlaneStacking; }
             else if (dih <= 60.0) code = ARP_PiTiltedStacking;
             else if (dih <= 90.0) { if (theta >= 30.0 && theta < 60.0) code = ARP_PiLStacking; else if (dist <= 5.0) code = ARP_PiTStacking; }
             if (code >= 0) rows.push_back(Row{(uint32_t)k1.model_serial, code, dist, entity_from_ring(k1), entity_from_ring(k2)});
-        }
+        });
     }
     lap("ring rows");
     // sort (mod.rs:120-134): model, from_chain, to_chain, from_resi, from_altloc, from_atomi, to_resi, to_altloc, to_atomi, interaction
