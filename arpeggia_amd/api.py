@@ -390,6 +390,6 @@ def contacts(input_file: str, groups: str = "/", vdw_comp: float = 0.1, dist_cut
     for signature compatibility (the reference sizes a rayon pool with it, utils.rs:8-30); the search and classification
     run on the GPU regardless.
     """
-    del num_threads
+    lib.arp_set_num_threads(int(num_threads))  # host threads of the table path (the reference's rayon pool); 0 = all
     s = Structure.load(input_file, ignore_zero_occupancy)
     return get_contacts(s, groups, vdw_comp, dist_cutoff)

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/arpeggia_amd.h"
@@ -74,4 +75,20 @@ arp_status parse_groups(const std::vector<std::string> &all_chains, const char *
                         std::vector<std::string> *receptor);
 arp_status apply_groups(arp_structure *s, const char *groups);
 bool fit_plane(const std::vector<std::array<double, 3>> &pts, Plane *out);
+
+// Host worker threads for the table path (planes, rows, sort, columns) -- the counterpart of the reference's global rayon pool
+// (utils.rs:8-30, python.rs num_threads).  1 = serial (the reference's default), 0 = all hardware threads.
+int host_threads();
+void set_host_threads(int n);
+// fn(begin, end, worker) over [0, n) in contiguous slices, one per worker; serial below `min_per_worker` items per worker.
+template <class F>
+void parallel_for(size_t n, size_t min_per_worker, F &&fn) {
+    size_t workers = (size_t)host_threads();
+    if (min_per_worker && n / min_per_worker < workers) workers = n / min_per_worker;
+    if (workers <= 1) { fn((size_t)0, n, (size_t)0); return; }
+    std::vector<std::thread> th;
+    th.reserve(workers);
+    for (size_t w = 0; w < workers; w++) th.emplace_back([&, w]() { fn(n * w / workers, n * (w + 1) / workers, w); });
+    for (auto &t : th) t.join();
+}
 }  // namespace arp

@@ -506,6 +506,17 @@ arp_status apply_groups(arp_structure *s, const char *groups) {
 using namespace arp;
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------
+namespace arp {
+static int g_host_threads = 1;
+int host_threads() { return g_host_threads; }
+void set_host_threads(int n) {
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    g_host_threads = std::max(1, std::min(n, 64));
+}
+}  // namespace arp
+extern "C" void arp_set_num_threads(int32_t n) { arp::set_host_threads(n); }
+extern "C" int32_t arp_get_num_threads(void) { return arp::host_threads(); }
+
 extern "C" void arp_default_params(arp_params *p) {
     if (!p) return;
     memset(p, 0, sizeof *p);

@@ -140,24 +140,38 @@ static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEn
     std::vector<int32_t> serials;
     for (const ChainInfo &c : s.chains) if (std::find(serials.begin(), serials.end(), c.model_serial) == serials.end()) serials.push_back(c.model_serial);
     // res2idx: (model serial, chain, resi, icode) -> residue
+    // With ONE model serial a plane entry can only resolve to the residue it was fitted from (the hierarchy holds one residue
+    // per (chain, resi, icode)); the keyed lookup below is needed for multi-model files only.
+    const bool one_model = serials.size() <= 1;
     std::unordered_map<PlaneKey, uint32_t, PlaneKeyHash> res_of;
-    res_of.reserve(s.residues.size() * 2);
-    for (uint32_t r = 0; r < s.residues.size(); r++) {
-        const ResidueInfo &ri = s.residues[r];
-        res_of[plane_key(s.chains[ri.chain].model_serial, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), "", "")] = r;
+    if (!one_model) {
+        res_of.reserve(s.residues.size() * 2);
+        for (uint32_t r = 0; r < s.residues.size(); r++) {
+            const ResidueInfo &ri = s.residues[r];
+            res_of[plane_key(s.chains[ri.chain].model_serial, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), "", "")] = r;
+        }
     }
     index->reserve(s.residues.size() * 2);
     // complex.rs:447-449 / 489-492: for EVERY model serial, ALL chains of ALL models are visited; later inserts overwrite
+    // the plane of a residue does not depend on the model serial it is filed under: fit once (in parallel), file per serial
+    std::vector<Plane> fitted(s.residues.size());
+    std::vector<char> has_plane(s.residues.size(), 0);
+    parallel_for(s.residues.size(), 512, [&](size_t r0, size_t r1, size_t) {
+        std::vector<std::array<double, 3>> pts;
+        for (size_t r = r0; r < r1; r++) {
+            const ResidueInfo &ri = s.residues[r];
+            const char *names = rings ? ring_atoms_of(ri.name) : sc_atoms_of(ri.name);
+            if (!names || ri.atoms.empty()) continue;
+            pts.clear();
+            for (uint32_t a : ri.atoms) if (in_words(names, s.name.at(a))) pts.push_back({s.x[a], s.y[a], s.z[a]});
+            has_plane[r] = fit_plane(pts, &fitted[r]) ? 1 : 0;  // complex.rs:471-474 warning path / :506 None
+        }
+    });
     for (int32_t m : serials)
         for (uint32_t r = 0; r < s.residues.size(); r++) {
             const ResidueInfo &ri = s.residues[r];
-            const char *names = rings ? ring_atoms_of(ri.name) : sc_atoms_of(ri.name);
-            if (rings && !names) continue;
-            if (ri.atoms.empty()) continue;
-            std::vector<std::array<double, 3>> pts;
-            if (names) for (uint32_t a : ri.atoms) if (in_words(names, s.name.at(a))) pts.push_back({s.x[a], s.y[a], s.z[a]});
-            Plane pl;
-            if (!fit_plane(pts, &pl)) continue;  // complex.rs:471-474 warning path / :506 None
+            if (!has_plane[r]) continue;
+            const Plane &pl = fitted[r];
             for (const std::string &alt : ri.altlocs) {
                 const PlaneKey key = plane_key(m, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), alt.c_str(), ri.name.c_str());
                 auto it = index->find(key);
@@ -165,9 +179,10 @@ static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEn
                 PlaneEntry &e = (*out)[it->second];
                 e.model_serial = m; e.chain = s.chains[ri.chain].id; e.resi = ri.resi; e.icode = ri.icode; e.altloc = alt; e.resn = ri.name;
                 e.plane = pl;
+                if (one_model) { e.has_ord = true; e.ord = ri.ord; }
             }
         }
-    for (PlaneEntry &e : *out) {
+    if (!one_model) for (PlaneEntry &e : *out) {
         auto it = res_of.find(plane_key(e.model_serial, e.chain.c_str(), e.resi, e.icode.c_str(), "", ""));
         if (it == res_of.end()) continue;
         const ResidueInfo &ri = s.residues[it->second];
@@ -264,19 +279,23 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     // per-atom side-chain plane lookup (the join key of mod.rs:100-110 plus resn, as in collect_sc_stats)
     std::vector<int64_t> atom_sc(s->n, -1);
     {
-        // per (residue, altloc) lookups are repeated per atom: memoise on residue id + the (<= 3 byte) altloc
-        std::unordered_map<uint64_t, int64_t> memo;
-        for (size_t a = 0; a < s->n; a++) {
-            uint32_t alt = 0;
-            memcpy(&alt, s->altloc.at(a), 4);
-            const uint64_t key = ((uint64_t)s->res_id[a] << 32) | alt;
-            auto it = memo.find(key);
-            if (it == memo.end()) {
-                auto f = sc_idx.find(plane_key(s->model_serial[a], s->chain.at(a), s->resi[a], s->icode.at(a), s->altloc.at(a), s->res_resn.at(a)));
-                it = memo.emplace(key, f == sc_idx.end() ? -1 : (int64_t)f->second).first;
+        // one lookup per (residue, conformer altloc); the residue's atoms pick theirs by altloc
+        parallel_for(s->residues.size(), 2048, [&](size_t r0, size_t r1, size_t) {
+            std::vector<int64_t> plane_of_alt;
+            for (size_t r = r0; r < r1; r++) {
+                const ResidueInfo &ri = s->residues[r];
+                if (ri.atoms.empty()) continue;
+                const uint32_t a0 = ri.atoms[0];
+                plane_of_alt.assign(ri.altlocs.size(), -1);
+                for (size_t k = 0; k < ri.altlocs.size(); k++) {
+                    auto f = sc_idx.find(plane_key(s->model_serial[a0], s->chain.at(a0), s->resi[a0], s->icode.at(a0), ri.altlocs[k].c_str(), s->res_resn.at(a0)));
+                    if (f != sc_idx.end()) plane_of_alt[k] = (int64_t)f->second;
+                }
+                for (uint32_t a : ri.atoms)
+                    for (size_t k = 0; k < ri.altlocs.size(); k++)
+                        if (strcmp(s->altloc.at(a), ri.altlocs[k].c_str()) == 0) { atom_sc[a] = plane_of_alt[k]; break; }
             }
-            atom_sc[a] = it->second;
-        }
+        });
     }
     auto entity_from_atom = [&](uint32_t a) {  // structs.rs:109-119
         Entity e;
@@ -295,13 +314,27 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
         e.sc_plane = f == sc_idx.end() ? -1 : (int64_t)f->second;
         return e;
     };
+    // one row per set bit: a prefix count gives every worker its own output range (rows keep the pair order)
     std::vector<Row> rows;
-    rows.reserve(pairs.n / 8 + 64);
-    for (uint64_t k = 0; k < pairs.n; k++) {
-        const arp_pair &p = pairs.data[k];
-        if (!p.kind) continue;
-        for (int b = 0; b < ARP_N_INTERACTIONS; b++)
-            if (p.kind & (1u << b)) rows.push_back(Row{(uint32_t)s->model_serial[p.i], b, (double)p.dist, entity_from_atom(p.i), entity_from_atom(p.j)});
+    {
+        const size_t workers = (size_t)std::max(1, host_threads());
+        std::vector<uint64_t> first(workers + 1, 0);
+        parallel_for((size_t)pairs.n, 1u << 15, [&](size_t k0, size_t k1, size_t w) {
+            uint64_t c = 0;
+            for (size_t k = k0; k < k1; k++) c += (uint64_t)__builtin_popcount(pairs.data[k].kind);
+            first[w + 1] = c;
+        });
+        for (size_t w = 0; w < workers; w++) first[w + 1] += first[w];
+        rows.reserve(first[workers] + 4 * rings.size() + 64);  // the ring rows are appended later: no regrowth of ~100-byte rows
+        rows.resize(first[workers]);
+        parallel_for((size_t)pairs.n, 1u << 15, [&](size_t k0, size_t k1, size_t w) {
+            Row *out_row = rows.data() + first[w];
+            for (size_t k = k0; k < k1; k++) {
+                const arp_pair &p = pairs.data[k];
+                for (uint32_t bits = p.kind; bits; bits &= bits - 1u)
+                    *out_row++ = Row{(uint32_t)s->model_serial[p.i], __builtin_ctz(bits), (double)p.dist, entity_from_atom(p.i), entity_from_atom(p.j)};
+            }
+        });
     }
     arp_pairs_free(&pairs);
     lap("atom rows");
@@ -396,12 +429,14 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     };
     auto be32 = [](const char *p) { return ((uint32_t)(unsigned char)p[0] << 24) | ((uint32_t)(unsigned char)p[1] << 16) | ((uint32_t)(unsigned char)p[2] << 8) | (uint32_t)(unsigned char)p[3]; };
     std::vector<SortKey> keys(rows.size());
-    for (size_t k = 0; k < rows.size(); k++) {
+    parallel_for(rows.size(), 1u << 14, [&](size_t k0, size_t k1, size_t) {
+    for (size_t k = k0; k < k1; k++) {
         const Row &r = rows[k];
         keys[k] = SortKey{r.model, r.from.chain_rank, r.to.chain_rank, r.from.resi, be32(r.from.altloc), r.from.atomi, r.to.resi, be32(r.to.altloc),
                           r.to.atomi, name_rank[r.interaction], be32(r.from.insertion), be32(r.to.insertion), r.distance, (uint32_t)k};
     }
-    std::sort(keys.begin(), keys.end(), [](const SortKey &a, const SortKey &b) {
+    });
+    auto key_less = [](const SortKey &a, const SortKey &b) {
         if (a.model != b.model) return a.model < b.model;
         if (a.from_chain != b.from_chain) return a.from_chain < b.from_chain;
         if (a.to_chain != b.to_chain) return a.to_chain < b.to_chain;
@@ -417,7 +452,25 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
         if (a.to_ins != b.to_ins) return a.to_ins < b.to_ins;
         if (a.distance != b.distance) return a.distance < b.distance;
         return a.idx < b.idx;
-    });
+    };
+    {   // slices sorted by the workers, then merged pairwise (the order is total, so the result does not depend on the slicing)
+        std::vector<size_t> cut{0};
+        size_t workers = (size_t)std::max(1, host_threads());
+        if (keys.size() / (1u << 14) < workers) workers = std::max<size_t>(1, keys.size() / (1u << 14));
+        for (size_t w = 1; w <= workers; w++) cut.push_back(keys.size() * w / workers);
+        parallel_for(workers, 1, [&](size_t w0, size_t w1, size_t) {
+            for (size_t w = w0; w < w1; w++) std::sort(keys.begin() + cut[w], keys.begin() + cut[w + 1], key_less);
+        });
+        for (size_t step = 1; step < workers; step *= 2) {
+            const size_t n_merges = (workers + 2 * step - 1) / (2 * step);
+            parallel_for(n_merges, 1, [&](size_t m0, size_t m1, size_t) {
+                for (size_t m = m0; m < m1; m++) {
+                    const size_t lo = m * 2 * step, mid = std::min(lo + step, workers), hi = std::min(lo + 2 * step, workers);
+                    if (mid < hi) std::inplace_merge(keys.begin() + cut[lo], keys.begin() + cut[mid], keys.begin() + cut[hi], key_less);
+                }
+            });
+        }
+    }
     std::vector<uint32_t> order(rows.size());
     for (size_t k = 0; k < rows.size(); k++) order[k] = keys[k].idx;
     lap("sort");
@@ -428,9 +481,10 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     t->from_atom.resize(n); t->to_atom.resize(n); t->distance.resize(n); t->sc_dist.resize(n); t->sc_dihedral.resize(n); t->sc_angle.resize(n); t->sc_valid.resize(n);
     t->from_chain.resize(n); t->from_resn.resize(n); t->from_atomn.resize(n); t->to_chain.resize(n); t->to_resn.resize(n); t->to_atomn.resize(n);
     t->from_insertion.resize(n); t->from_altloc.resize(n); t->to_insertion.resize(n); t->to_altloc.resize(n);
+    parallel_for(n, 1u << 14, [&](size_t k_begin, size_t k_end, size_t) {
     uint64_t last_pair = ~0ull;
     float last_sc[3] = {0.f, 0.f, 0.f};
-    for (size_t k = 0; k < n; k++) {
+    for (size_t k = k_begin; k < k_end; k++) {
         const Row &r = rows[order[k]];
         t->model[k] = r.model; t->interaction[k] = r.interaction; t->distance[k] = (float)r.distance;  // mod.rs:148
         t->from_chain.set(k, r.from.chain); t->from_resn.set(k, r.from.resn); t->from_atomn.set(k, r.from.atomn);
@@ -451,6 +505,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
             t->sc_dist[k] = last_sc[0]; t->sc_dihedral[k] = last_sc[1]; t->sc_angle[k] = last_sc[2];
         }
     }
+    });
     lap("columns + sc stats");
     *out = t;
     return ARP_OK;

@@ -192,6 +192,12 @@ arp_status arp_structure_atoms(arp_structure *s, const char *groups, arp_atoms *
 const char *arp_structure_strings(const arp_structure *s, const char *column, int32_t *width);
 const int32_t *arp_structure_ints(const arp_structure *s, const char *column);
 
+/* Host worker threads of the table path (plane fits, row assembly, sort, columns): the reference's global rayon pool
+ * (utils.rs:8-30; `num_threads` of python.rs:31).  1 = serial (default, as in the reference), 0 = all hardware threads.
+ * The GPU search and classification do not depend on it. */
+void arp_set_num_threads(int32_t n);
+int32_t arp_get_num_threads(void);
+
 /* ---- the table: replaces arpeggia::get_contacts (mod.rs:61-137) ---- */
 arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp,
                             double dist_cutoff, arp_table **out);

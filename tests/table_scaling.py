@@ -13,8 +13,16 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 rec = synth.gen_s1(n)
 s = aa.Structure.from_records(rec, hierarchy=True)
 ctx = aa.Context(0)
-ctx.get_contacts(s)
-t0 = time.perf_counter()
-cols = ctx.get_contacts(s)
-dt = time.perf_counter() - t0
-print(f"S1 {s.n_atoms} atoms: get_contacts {dt * 1e3:.1f} ms, {len(cols['model'])} rows", file=sys.stderr)
+from arpeggia_amd import _lib  # noqa: E402
+
+ref = None
+for threads in (1, 4, 16):
+    _lib.lib.arp_set_num_threads(threads)
+    ctx.get_contacts(s)
+    t0 = time.perf_counter()
+    cols = ctx.get_contacts(s)
+    dt = time.perf_counter() - t0
+    print(f"S1 {s.n_atoms} atoms, {threads} host thread(s): get_contacts {dt * 1e3:.1f} ms, {len(cols['model'])} rows", file=sys.stderr)
+    key = tuple(cols[c].tobytes() for c in ("model", "interaction", "distance", "from_atom", "to_atom", "sc_dihedral"))
+    assert ref is None or key == ref, "the table must not depend on the thread count"
+    ref = key

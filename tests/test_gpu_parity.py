@@ -478,6 +478,27 @@ def test_table_on_stress_structure_matches_oracle_table(ctx, tmp_path):
         _lines_close(_table_lines(cols), want)
 
 
+def test_table_multi_model_and_host_threads(ctx, tmp_path):
+    """Two models (the plane tables visit all chains of all models under every model serial, complex.rs:447-449) against the
+    oracle's table, and the same table for 1 and 8 host threads."""
+    rec = synth.gen_stress(n_res=150, seed=33, n_models=2, n_chains=2)
+    p = tmp_path / "two_models.pdb"
+    synth.write_pdb(rec, p)
+    s, o = aa.load_model(p), ob.Structure.load(p)
+    want = ob.rows_to_csv_lines(o.get_contacts("/", 0.1, 6.5))
+    tables = []
+    try:
+        for threads in (1, 8):
+            _lib.lib.arp_set_num_threads(threads)
+            assert _lib.lib.arp_get_num_threads() == threads
+            cols = ctx.get_contacts(s, "/", 0.1, 6.5)
+            _lines_close(_table_lines(cols), want)
+            tables.append(_table_lines(cols))
+    finally:
+        _lib.lib.arp_set_num_threads(1)
+    assert tables[0] == tables[1]
+
+
 def test_no_ring_structure_is_an_error(ctx):
     # complex.rs:50,480-482: panics when the model has no HIS/PHE/TYR/TRP ring
     prod, orc = _both_from(_mini([[0, 0, 0], [3, 0, 0], [0, 3, 0]]))
