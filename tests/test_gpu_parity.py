@@ -499,6 +499,17 @@ def test_table_multi_model_and_host_threads(ctx, tmp_path):
     assert tables[0] == tables[1]
 
 
+def test_cli_contacts_end_to_end(ctx, tmp_path):
+    # cli/contacts.rs:54-138: <output>/<filename>.<format>, 532 rows + header for 1ubq
+    from arpeggia_amd.__main__ import main
+
+    rc = main(["contacts", "-i", str(synth.DATA / "1ubq.pdb"), "-o", str(tmp_path / "out"), "-f", "ubq", "-t", "csv"])
+    assert rc == 0
+    lines = (tmp_path / "out" / "ubq.csv").read_text().splitlines()
+    assert len(lines) == 533 and lines[0].replace('"', "").split(",") == [c for c, _ in aa.TABLE_COLUMNS]
+    assert main(["contacts", "-i", str(tmp_path / "missing.pdb"), "-o", str(tmp_path / "out")]) == 1
+
+
 def test_no_ring_structure_is_an_error(ctx):
     # complex.rs:50,480-482: panics when the model has no HIS/PHE/TYR/TRP ring
     prod, orc = _both_from(_mini([[0, 0, 0], [3, 0, 0], [0, 3, 0]]))

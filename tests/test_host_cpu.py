@@ -184,3 +184,34 @@ def test_mmcif_reader(tmp_path, ubq_path):
     for k in ("x", "y", "z", "attr", "res_ord", "res_id", "chain_rank"):
         assert np.array_equal(sa[k], sb[k]), k
     assert (a.ints("model") == 1).all()
+
+
+def test_cli_flags_and_defaults_match_the_reference():
+    # src/cli/contacts.rs:9-52: -i -o required; -g "/", -f "contacts", -t csv, -c 0.1, -d 6.5, -j 1, --ignore-zero-occupancy false
+    from arpeggia_amd.__main__ import FORMATS, build_parser
+
+    a = build_parser().parse_args(["contacts", "-i", "m.pdb", "-o", "out"])
+    assert (a.groups, a.filename, a.output_format, a.vdw_comp, a.dist_cutoff, a.num_threads, a.ignore_zero_occupancy) == ("/", "contacts", "csv", 0.1, 6.5, 1, False)
+    b = build_parser().parse_args(["contacts", "--input", "m.cif", "--output", "o", "-g", "A,B/C", "-f", "x", "-t", "Parquet", "-c", "0.2", "-d", "5", "-j", "0",
+                                   "--ignore-zero-occupancy"])
+    assert (b.groups, b.filename, b.output_format, b.vdw_comp, b.dist_cutoff, b.num_threads, b.ignore_zero_occupancy) == ("A,B/C", "x", "parquet", 0.2, 5.0, 0, True)
+    assert FORMATS == ("csv", "parquet", "json", "ndjson")  # utils.rs:159-167
+    with pytest.raises(SystemExit):
+        build_parser().parse_args(["contacts", "-o", "out"])
+
+
+def test_cli_writers(tmp_path):
+    import json
+
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from arpeggia_amd.__main__ import write_table
+
+    t = pa.table({"model": pa.array([0, 0], pa.uint32()), "interaction": ["VanDerWaalsContact", "PolarContact"], "distance": pa.array([3.5, 2.9], pa.float32()),
+                  "sc_dihedral": pa.array([12.5, None], pa.float32())})
+    for fmt in ("csv", "parquet", "json", "ndjson"):
+        write_table(t, tmp_path / f"c.{fmt}", fmt)
+    assert (tmp_path / "c.csv").read_text().splitlines()[0].replace('"', "") == "model,interaction,distance,sc_dihedral"
+    assert pq.read_table(tmp_path / "c.parquet").equals(t)
+    assert json.loads((tmp_path / "c.json").read_text())[1]["sc_dihedral"] is None
+    assert [json.loads(line)["interaction"] for line in (tmp_path / "c.ndjson").read_text().splitlines()] == ["VanDerWaalsContact", "PolarContact"]
