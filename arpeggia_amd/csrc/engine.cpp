@@ -87,11 +87,14 @@ struct arp_context {
     Workspace ws{};
     std::vector<void *> ws_allocs;
     // device staging of host inputs
+    // host inputs travel as ONE block: the twelve arrays are packed into a pinned buffer and cross PCIe in a single copy
+    // (twelve small pageable copies cost ~100 us of launch overhead on a PDB-sized structure)
     struct Staged {
-        void *x = nullptr, *y = nullptr, *z = nullptr, *attr = nullptr, *res_ord = nullptr, *chain_rank = nullptr, *model = nullptr;
-        void *res_id = nullptr, *res_h_ptr = nullptr, *res_h_idx = nullptr, *res_cb = nullptr, *res_sg = nullptr;
-        uint64_t n_cap = 0, nres_cap = 0, nh_cap = 0;
+        char *dev = nullptr, *pinned = nullptr;
+        uint64_t bytes = 0;
     } st;
+    arp_pair *out_buf = nullptr;            // reusable device output of the host-output path (grow-only)
+    uint64_t out_cap = 0;
     DevParams *h_params = nullptr;         // pinned
     unsigned long long *h_result = nullptr;  // pinned [2]
     arp_params last_params{};
@@ -173,8 +176,8 @@ extern "C" arp_status arp_context_create(int32_t device, arp_context **out) {
 
 static void free_staged(arp_context *ctx) {
     auto &s = ctx->st;
-    void *ps[] = {s.x, s.y, s.z, s.attr, s.res_ord, s.chain_rank, s.model, s.res_id, s.res_h_ptr, s.res_h_idx, s.res_cb, s.res_sg};
-    for (void *p : ps) if (p) (void)hipFree(p);
+    if (s.dev) (void)hipFree(s.dev);
+    if (s.pinned) (void)hipHostFree(s.pinned);
     s = arp_context::Staged{};
 }
 
@@ -184,6 +187,7 @@ extern "C" void arp_context_destroy(arp_context *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_workspace(ctx);
     free_staged(ctx);
+    if (ctx->out_buf) (void)hipFree(ctx->out_buf);
     if (ctx->h_params) (void)hipHostFree(ctx->h_params);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->prof.created) for (int k = 0; k < Profiler::kMax; k++) { (void)hipEventDestroy(ctx->prof.ev0[k]); (void)hipEventDestroy(ctx->prof.ev1[k]); }
@@ -218,13 +222,6 @@ static arp_status validate(const arp_atoms *a, const arp_params *p) {
     return ARP_OK;
 }
 
-template <typename T>
-static arp_status stage(void **dst, const T *src, uint64_t count, hipStream_t st) {
-    if (!count) return ARP_OK;
-    HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, st));
-    return ARP_OK;
-}
-
 static arp_status stage_inputs(arp_context *ctx, const arp_atoms *a, DevAtoms *d) {
     d->n = (uint32_t)a->n;
     d->n_res = (uint32_t)a->n_res;
@@ -237,35 +234,31 @@ static arp_status stage_inputs(arp_context *ctx, const arp_atoms *a, DevAtoms *d
     uint64_t nh = 0;
     if (a->n_res) nh = a->res_h_ptr[a->n_res];
     if (nh && !a->res_h_idx) { set_error("null res_h_idx"); return ARP_ERR_BAD_INPUT; }
-    if (s.n_cap < a->n || s.nres_cap < a->n_res || s.nh_cap < nh) {
+    // layout of the block: 256-byte aligned segments
+    struct Seg { const void *src; uint64_t bytes, off; };
+    const uint64_t n = a->n, nr = a->n_res;
+    Seg seg[12] = {{a->x, n * 8, 0}, {a->y, n * 8, 0}, {a->z, n * 8, 0}, {a->attr, n * 4, 0}, {a->res_ord, n * 4, 0}, {a->chain_rank, n * 2, 0},
+                   {a->model, n * 2, 0}, {nr ? a->res_id : nullptr, nr ? n * 4 : 0, 0}, {nr ? a->res_h_ptr : nullptr, nr ? (nr + 1) * 4 : 0, 0},
+                   {nr ? a->res_cb : nullptr, nr * 4, 0}, {nr ? a->res_sg : nullptr, nr * 4, 0}, {nh ? a->res_h_idx : nullptr, nh * 4, 0}};
+    uint64_t total = 0;
+    for (Seg &g : seg) { g.off = total; total += (g.bytes + 255u) & ~255ull; }
+    total = std::max<uint64_t>(total, 256);
+    if (s.bytes < total) {
         (void)hipStreamSynchronize(ctx->stream);
         free_staged(ctx);
-        uint64_t nc = std::max<uint64_t>(a->n + a->n / 8, 1024), rc = std::max<uint64_t>(a->n_res + a->n_res / 8, 16), hc = std::max<uint64_t>(nh + nh / 8, 16);
-        HIP_TRY(hipMalloc(&s.x, nc * 8)); HIP_TRY(hipMalloc(&s.y, nc * 8)); HIP_TRY(hipMalloc(&s.z, nc * 8));
-        HIP_TRY(hipMalloc(&s.attr, nc * 4)); HIP_TRY(hipMalloc(&s.res_ord, nc * 4));
-        HIP_TRY(hipMalloc(&s.chain_rank, nc * 2)); HIP_TRY(hipMalloc(&s.model, nc * 2));
-        HIP_TRY(hipMalloc(&s.res_id, nc * 4));
-        HIP_TRY(hipMalloc(&s.res_h_ptr, (rc + 1) * 4)); HIP_TRY(hipMalloc(&s.res_cb, rc * 4)); HIP_TRY(hipMalloc(&s.res_sg, rc * 4));
-        HIP_TRY(hipMalloc(&s.res_h_idx, hc * 4));
-        s.n_cap = nc; s.nres_cap = rc; s.nh_cap = hc;
+        const uint64_t cap = total + total / 8;
+        HIP_TRY(hipMalloc((void **)&s.dev, cap));
+        HIP_TRY(hipHostMalloc((void **)&s.pinned, cap, hipHostMallocDefault));
+        s.bytes = cap;
     }
-    hipStream_t st = ctx->stream;
-    arp_status r;
-    if ((r = stage(&s.x, a->x, a->n, st)) || (r = stage(&s.y, a->y, a->n, st)) || (r = stage(&s.z, a->z, a->n, st)) ||
-        (r = stage(&s.attr, a->attr, a->n, st)) || (r = stage(&s.res_ord, a->res_ord, a->n, st)) ||
-        (r = stage(&s.chain_rank, a->chain_rank, a->n, st)) || (r = stage(&s.model, a->model, a->n, st)))
-        return r;
-    if (a->n_res) {
-        if ((r = stage(&s.res_id, a->res_id, a->n, st)) || (r = stage(&s.res_h_ptr, a->res_h_ptr, a->n_res + 1, st)) ||
-            (r = stage(&s.res_cb, a->res_cb, a->n_res, st)) || (r = stage(&s.res_sg, a->res_sg, a->n_res, st)) ||
-            (r = stage(&s.res_h_idx, a->res_h_idx, nh, st)))
-            return r;
-    }
-    d->x = (const double *)s.x; d->y = (const double *)s.y; d->z = (const double *)s.z;
-    d->attr = (const uint32_t *)s.attr; d->res_ord = (const uint32_t *)s.res_ord;
-    d->chain_rank = (const uint16_t *)s.chain_rank; d->model = (const uint16_t *)s.model;
-    d->res_id = (const uint32_t *)s.res_id; d->res_h_ptr = (const uint32_t *)s.res_h_ptr; d->res_h_idx = (const uint32_t *)s.res_h_idx;
-    d->res_cb = (const uint32_t *)s.res_cb; d->res_sg = (const uint32_t *)s.res_sg;
+    for (const Seg &g : seg) if (g.bytes) memcpy(s.pinned + g.off, g.src, g.bytes);
+    HIP_TRY(hipMemcpyAsync(s.dev, s.pinned, total, hipMemcpyHostToDevice, ctx->stream));
+    auto at = [&](int k) -> const void * { return s.dev + seg[k].off; };
+    d->x = (const double *)at(0); d->y = (const double *)at(1); d->z = (const double *)at(2);
+    d->attr = (const uint32_t *)at(3); d->res_ord = (const uint32_t *)at(4);
+    d->chain_rank = (const uint16_t *)at(5); d->model = (const uint16_t *)at(6);
+    d->res_id = (const uint32_t *)at(7); d->res_h_ptr = (const uint32_t *)at(8); d->res_cb = (const uint32_t *)at(9); d->res_sg = (const uint32_t *)at(10);
+    d->res_h_idx = (const uint32_t *)at(11);
     return ARP_OK;
 }
 
@@ -347,6 +340,40 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
+    if (out_location == ARP_MEM_HOST && !(params->flags & ARP_FLAG_DETERMINISTIC)) {
+        // Host output, single-pass emitter: ONE pass into the context's reusable device buffer -- no count pass, no
+        // hipMalloc/hipFree per call (together ~half of the latency of a PDB-sized structure).  A buffer that turns out too
+        // small only makes the pass report the size (k_fixup); it is then grown and the pass repeated.
+        // first guess: 64 records per atom (twice the all-pairs density of a protein), at most 2 GiB; a larger result costs one more pass
+        uint64_t want = std::max<uint64_t>(ctx->out_cap, std::min<uint64_t>(std::max<uint64_t>(64 * (uint64_t)atoms->n, 1u << 16), 1u << 27));
+        unsigned long long total = 0;
+        for (int attempt = 0;; attempt++) {
+            if (ctx->out_cap < want) {
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+                ctx->out_buf = nullptr; ctx->out_cap = 0;
+                HIP_TRY(hipMalloc((void **)&ctx->out_buf, want * sizeof(arp_pair)));
+                ctx->out_cap = want;
+            }
+            launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false);
+            launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
+            total = ctx->h_result[0];
+            if (total <= ctx->out_cap) break;
+            if (attempt) { set_error("internal error: pair count changed between passes"); return ARP_ERR_HIP; }
+            want = total + total / 8;
+        }
+        if (total == 0) return ARP_OK;
+        arp_pair *host = (arp_pair *)malloc(total * sizeof(arp_pair));
+        if (!host) { set_error("out of host memory"); return ARP_ERR_OOM; }
+        hipError_t e = hipMemcpy(host, ctx->out_buf, total * sizeof(arp_pair), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(host); set_error("HIP error %d copying pairs to the host", (int)e); return ARP_ERR_HIP; }
+        out->data = host; out->n = total;
+        return ARP_OK;
+    }
     // count pass -> output size -> ordered fill or single-pass emit.  With ARP_FLAG_CONTACTS_ONLY the single-pass emitter
     // sizes the device buffer by the (cheap) candidate count, an upper bound; the ordered one needs the exact filtered counts.
     const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
