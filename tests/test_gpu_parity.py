@@ -127,6 +127,48 @@ def test_cys_without_cb_is_an_error_like_the_reference_panic(ctx):
     assert e.value.status == _lib.ARP_ERR_BAD_INPUT
 
 
+@pytest.mark.parametrize("case", range(24))
+def test_randomised_structures_and_parameters(ctx, case):
+    """Random sizes, densities, chain groups, cutoffs and compensation factors: every combination goes through both emitters,
+    the contacts-only filter and the oracle (covers the probe hand-off of the hot kernel on hydrogen-rich and hydrogen-free input)."""
+    rng = np.random.default_rng(9000 + case)
+    n_res = int(rng.integers(40, 700))
+    n_chains = int(rng.integers(1, 6))
+    kw = dict(n_res=n_res, seed=500 + case, box=float(rng.uniform(14.0, 60.0)), hydrogens=bool(rng.integers(0, 2)), n_models=int(rng.integers(1, 3)),
+              n_chains=n_chains, altlocs=bool(rng.integers(0, 4) == 0))
+    chains = [chr(ord("A") + c) for c in range(n_chains)]
+    pick = lambda: ",".join(sorted(rng.choice(chains, size=int(rng.integers(1, n_chains + 1)), replace=False)))
+    groups = ["/", pick() + "/", "/" + pick(), pick() + "/" + pick()][int(rng.integers(0, 4))]
+    vdw_comp, cutoff = float(rng.choice([0.0, 0.05, 0.1, 0.3])), float(rng.choice([3.0, 4.4, 4.5, 5.0, 6.5, 8.0]))
+    rec = synth.gen_stress(**kw)
+    prod = aa.Structure.from_records(rec)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+    try:
+        want = orc.atomic_contacts(groups, vdw_comp, cutoff)
+    except ob.OracleError:  # a CYS SG..SG pair without CB (the reference panics): the product must refuse too
+        with pytest.raises(aa.ArpeggiaError):
+            ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff))
+        return
+    what = f"{kw} groups={groups} c={vdw_comp} d={cutoff}"
+    for det in (False, True):
+        assert_pairs_equal(ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff, deterministic=det)), want, what)
+        only = ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff, deterministic=det, contacts_only=True))
+        assert_pairs_equal(only, want[want["kind"] != 0], what + " contacts-only")
+
+
+def test_hydrogen_rich_medium_structure(ctx):
+    # 5000 residues with explicit hydrogens (~63k atoms): the deferred probe pass carries a large share of the pairs
+    rec = synth.gen_stress(n_res=5000, seed=77, box=28.0 * (5000 / 400.0) ** (1.0 / 3.0))
+    prod = aa.Structure.from_records(rec)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+    got, want = run_both(ctx, prod, orc)
+    assert len(want) > 1_000_000
+    assert_pairs_equal(got, want, "hydrogen-rich 5000 residues")
+    seen = np.bitwise_or.reduce(want["kind"])
+    for name in ("HydrogenBond", "WeakHydrogenBond", "SaltBridge", "Disulfide"):
+        assert seen & (1 << ob.INTERACTIONS.index(name)), name
+
+
 # ---------------------------------------------------------------------------------------------- synthetic clouds
 @pytest.mark.parametrize("gen,n", [("s2", 20000), ("s1", 20000), ("s2", 100000), ("s1", 100000)])
 def test_synthetic_clouds_vs_oracle(ctx, gen, n):
