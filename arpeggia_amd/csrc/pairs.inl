@@ -174,7 +174,15 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
 #endif
                 const Slots sl = alloc_chunked<kChunkRecords>(bl.alloc_state, &result[2], n, lane);
                 const uint32_t rank = mbcnt(vm);
-                if (valid) {
+                if (sl.n0 == n && sl.pos0 + n <= tg.capacity) {
+                    // the common case, decided on the scalar unit: one run inside the caller's buffer -> scalar base + 32-bit lane offset
+                    uint4 *run = reinterpret_cast<uint4 *>(tg.out) + sl.pos0;
+#if defined(ARP_ABLATE) && ARP_ABLATE == 11
+                    if (valid && r.w == 0xDEADBEEFu) run[rank] = r;
+#else
+                    if (valid) run[rank] = r;
+#endif
+                } else if (valid) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
                     uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
 #if defined(ARP_ABLATE) && ARP_ABLATE == 11   // timing ablation: allocation but no store
                     if (d && r.w == 0xDEADBEEFu) *d = r;
