@@ -109,7 +109,8 @@ struct Profiler {
 // Launch wrappers (kernels.hip / pairs.inl).  All asynchronous on `st`.
 void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered);
 void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out, bool contacts_only);
-void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
+void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof,
+                         bool contacts_only);
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 unsigned long long emit_scratch_records();
 

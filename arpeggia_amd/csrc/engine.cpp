@@ -142,7 +142,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
-    w.defer_cap = std::max<uint64_t>(8 * cap, 1u << 20) + (1u << 20); A(w.defer_list, w.defer_cap);  // + one partly used 512-entry chunk per block
+    w.defer_cap = std::max<uint64_t>(16 * cap, 1u << 20) + (1u << 20); A(w.defer_list, w.defer_cap);  // + one partly used 512-entry chunk per block
 #undef A
     w.n_cap = (uint32_t)cap;
     w.ncells_cap = (uint32_t)ccap;
@@ -277,7 +277,7 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
 static arp_status flags_to_status(unsigned long long flags) {
     if (flags & 4ull) { set_error("non-finite atom coordinate"); return ARP_ERR_BAD_INPUT; }
     if (flags & 16ull) { set_error("internal error: inconsistent hole plan in k_fixup"); return ARP_ERR_HIP; }
-    if (flags & 8ull) { set_error("deferred-probe list overflow; rerun with ARP_FLAG_DETERMINISTIC"); return ARP_ERR_CAPACITY; }
+    if (flags & 8ull) { set_error("deferred-probe list overflow (more than 8 probe candidates per atom); rerun with ARP_FLAG_DETERMINISTIC | ARP_FLAG_CONTACTS_ONLY"); return ARP_ERR_CAPACITY; }
     if (flags & 2ull) { set_error("CYS SG..SG covalent pair whose residue has no CB (the reference panics in is_disulfide, vdw.rs:58)"); return ARP_ERR_BAD_INPUT; }
     return ARP_OK;
 }
@@ -301,7 +301,7 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
         launch_count(d, ctx->ws, ctx->stream, prof, 0, true, only);  // size query: reports ARP_ERR_CAPACITY + the count
     } else if (params->flags & ARP_FLAG_DETERMINISTIC) {
         launch_count(d, ctx->ws, ctx->stream, prof, capacity, true, only);
-        launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof);
+        launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof, only);
     } else {
         launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof);
     }
@@ -387,7 +387,7 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     if (total == 0) return ARP_OK;
     arp_pair *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
-    if (params->flags & ARP_FLAG_DETERMINISTIC) launch_fill_ordered(d, ctx->ws, dev, total, ctx->stream, prof);
+    if (params->flags & ARP_FLAG_DETERMINISTIC) launch_fill_ordered(d, ctx->ws, dev, total, ctx->stream, prof, only);
     else launch_emit(d, ctx->ws, dev, total, ctx->stream, prof);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);

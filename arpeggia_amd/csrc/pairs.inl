@@ -148,6 +148,22 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
         if (MODE == kFillOrdered) {
             const unsigned long long pos = base + emitted + mbcnt(vm);
             if (valid && pos < tg.capacity) reinterpret_cast<uint4 *>(tg.out)[pos] = r;
+            if (!PROBES) {
+                // Fast ordered fill: a record whose rules need a probe is written with a placeholder kind at its final position
+                // and listed as {entry, position} -- two list slots, allocated in even counts so that a pair never straddles a
+                // chunk -- for k_patch_deferred, which overwrites the kind in place.
+                const bool defer = valid && r.w == kDeferKind && pos < tg.capacity;
+                const unsigned long long dm = __ballot(defer);
+                if (dm) {
+                    const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], 2u * (uint32_t)__popcll(dm), lane);
+                    if (defer) {
+                        const uint32_t dr = 2u * mbcnt(dm);
+                        const unsigned long long p = dr < ds.n0 ? ds.pos0 + dr : ds.pos1 + (dr - ds.n0);
+                        if (p + 1ull < tg.defer_cap) { tg.defer_list[p] = ent; tg.defer_list[p + 1ull] = make_uint2((uint32_t)pos, (uint32_t)(pos >> 32)); }
+                        else atomicOr(&result[1], 8ull);
+                    }
+                }
+            }
         } else {
             if (!PROBES) {
                 const bool defer = valid && r.w == kDeferKind;
@@ -200,7 +216,7 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
 // Block epilogue of the emit mode: the unused tail of the block's last chunk is its (one) hole.  Every wave must call it.
 DEVFN void emit_epilogue(BlockLds &bl, ulonglong2 *hole, const EmitTarget &tg) {
     __syncthreads();
-    {   // unused tail of the block's last deferred-list chunk: sentinels the deferred pass skips
+    {   // unused tail of the block's last deferred-list chunk: sentinels the deferred passes skip
         const unsigned long long st = bl.defer_state;
         const uint32_t chunk = (uint32_t)(st >> 32), used = (uint32_t)st;
         if (chunk != 0xFFFFFFFFu)
@@ -219,7 +235,7 @@ DEVFN void emit_epilogue(BlockLds &bl, ulonglong2 *hole, const EmitTarget &tg) {
 }
 
 template <int MODE, bool PROBES>
-__global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? kEmitWavesPerSimd : 1) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
+__global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFillOrdered) && !PROBES) ? kEmitWavesPerSimd : 1) void k_pairs(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start,
                                                                Sorted so, uint32_t *task_count, const unsigned long long *task_base,
                                                                EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     __shared__ LdsParams prm;
@@ -372,6 +388,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (MODE == kEmit && !PROBES) ? k
     if (lane == 0) nxt = atomicAdd(ctr, kGrab);
     t0 = g_lo + group_waves * kGrab + __builtin_amdgcn_readfirstlane(nxt);
     }
+    if (MODE == kFillOrdered && !PROBES) emit_epilogue(bl, hole_list + blockIdx.x, tg);  // (its hole entry is unused: sentinels only)
     if (MODE == kEmit) {
         if (qlen) {
             const bool act = lane < qlen;
@@ -413,6 +430,34 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
         process_batch<kEmit, true>(in, prm, so, wl[wave], bl, ent, act, 0ull, 0u, tg, result, lane);
     }
     emit_epilogue(bl, hole_list + blockIdx.x, tg);
+}
+
+// The deferred pass of the fast ordered fill: {entry, position} pairs; the probes decide the kind, which is patched in place.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void k_patch_deferred(DevAtoms in, const DevParams *dprm, Sorted so, EmitTarget tg,
+                                                                         unsigned long long *result) {
+    __shared__ LdsParams prm;
+    {
+        const double *src = dprm->s_clash;
+        double *dst = prm.s_clash;
+        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
+        if (threadIdx.x == 0) {
+            prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
+            prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
+        }
+        __syncthreads();
+    }
+    const unsigned long long n = min(result[3] * kDeferChunk, tg.defer_cap) / 2ull;  // {entry, position} pairs
+    const uint4 *list = reinterpret_cast<const uint4 *>(tg.defer_list);
+    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint4 e = list[q];
+        if (e.x == 0xFFFFFFFFu) continue;  // chunk tail
+        const Fat a = so.fat[e.x], b = so.fat[e.y];
+        const double s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
+        const bool swap = orient(a, b) == 2;
+        const uint32_t kind = classify<true>(in, prm, s, a, b, swap, result);
+        const unsigned long long pos = ((unsigned long long)e.w << 32) | e.z;
+        reinterpret_cast<uint32_t *>(tg.out + pos)[3] = kind;
+    }
 }
 
 // Close the holes of the emit pass: with R = records reserved and P = R - sum(holes) valid ones, every hole slot below P
@@ -570,12 +615,25 @@ void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profi
 }
 
 // ordered fill: needs launch_count first
-void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
-    EmitTarget tg{out, capacity, nullptr, 0ull, nullptr, 0ull};
+void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof,
+                         bool contacts_only) {
     if (prof) prof->begin("pairs_fill", st);
-    hipLaunchKernelGGL((k_pairs<kFillOrdered, true>), dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+    if (contacts_only) {
+        // the filter needs every kind before a record is placed: probes inline (2 waves per SIMD)
+        EmitTarget tg{out, capacity, nullptr, 0ull, nullptr, 0ull};
+        hipLaunchKernelGGL((k_pairs<kFillOrdered, true>), dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
+                           (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
+                           (const unsigned long long *)ws.task_base, tg, ws.hole_list, ws.task_ctr, ws.result);
+        if (prof) prof->end(st);
+        return;
+    }
+    // every candidate keeps its place: fill at the emit kernel's occupancy, then patch the kinds that needed a probe
+    EmitTarget tg{out, capacity, nullptr, 0ull, ws.defer_list, ws.defer_cap};
+    hipLaunchKernelGGL((k_pairs<kFillOrdered, false>), dim3(blocks_for(in.n, kEmitBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
                        (const DevParams *)ws.params, (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count,
                        (const unsigned long long *)ws.task_base, tg, ws.hole_list, ws.task_ctr, ws.result);
+    if (prof) { prof->end(st); prof->begin("pairs_patch", st); }
+    hipLaunchKernelGGL(k_patch_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.result);
     if (prof) prof->end(st);
 }
 

@@ -85,7 +85,7 @@ typedef struct arp_atoms {
 
 /* arp_params.flags.  By default pairs are emitted in one pass in an unspecified order (like the reference, whose order is
  * that of an R*-tree walk + rayon, complex.rs:194-298).  DETERMINISTIC selects the two-pass count/scan/fill emitter
- * whose output order is a function of the input only (about 2x slower).
+ * whose output order is a function of the input only (about 1.5x slower).
  * CONTACTS_ONLY drops the candidates no rule matched (kind == 0) on the device: what is left is exactly the set of
  * pairs get_atomic_contacts turns into ResultEntry rows (complex.rs:208-297), typically 5-10% of the candidates, so the
  * copy to the host and the table assembly shrink by that factor.  arp_get_contacts uses it. */
