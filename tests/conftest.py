@@ -8,6 +8,12 @@ for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# a fresh clone has no built libraries yet: build them once (hipcc cross-compiles gfx950 without a GPU; ~20 s)
+if not (ROOT / "arpeggia_amd" / "libarpeggia_amd.so").exists() or not (ROOT / "oracle" / "liboracle.so").exists():
+    import __graft_entry__
+
+    __graft_entry__.build()
+
 DATA = ROOT / "tests" / "data"
 GOLDEN = ROOT / "tests" / "golden"
 
