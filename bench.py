@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--atoms", type=int, default=1_000_000)
     ap.add_argument("--workload", choices=["s2", "s1"], default="s2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-atoms", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-atoms", type=int, default=1_000_000,
+                    help="size of the CPU-baseline sample (default: the full 10^6-atom workload, ~10 s on one host thread)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-check", action="store_true", help="diagnostic (ablation) builds: do not assert the pair count")
     ap.add_argument("--deterministic", action="store_true", help="two-pass ordered emitter (ARP_FLAG_DETERMINISTIC)")
