@@ -53,6 +53,32 @@ DEVFN void push_pass(uint32_t &mask, float d2, float thr) {
     asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(thr) : "vcc");
 }
 
+// One compaction round in 8 vector instructions (hipcc's version of the same loop body takes 16-18: it carries the queue length
+// in a vector register and rebuilds the lane mask from a 0/1 value).  Every lane with a surviving test (mask != 0) appends
+// {home slot, neighbour slot of its highest set bit} to the LDS queue at byte address qaddr + 8 * (its rank among those lanes)
+// and clears the bit.  Returns the ballot of the lanes that appended.
+DEVFN unsigned long long compact_round(uint32_t &mask, uint32_t home_slot, uint32_t nb_minus, uint32_t qaddr) {
+    unsigned long long m, save;
+    uint32_t t, lz, slot, bm;
+    asm volatile(
+        "v_cmp_ne_u32 vcc, 0, %[mask]\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_ffbh_u32 %[lz], %[mask]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 3, %[qaddr]\n\t"
+        "v_add_u32 %[slot], %[nb], %[lz]\n\t"
+        "v_lshrrev_b32 %[bm], %[lz], %[top]\n\t"
+        "s_mov_b64 %[m], vcc\n\t"
+        "s_and_saveexec_b64 %[save], vcc\n\t"
+        "ds_write2_b32 %[t], %[home], %[slot] offset1:1\n\t"
+        "v_xor_b32 %[mask], %[mask], %[bm]\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [mask] "+v"(mask), [t] "=&v"(t), [lz] "=&v"(lz), [slot] "=&v"(slot), [bm] "=&v"(bm), [m] "=&s"(m), [save] "=&s"(save)
+        : [home] "v"(home_slot), [nb] "v"(nb_minus), [qaddr] "s"(qaddr), [top] "s"(0x80000000u)
+        : "vcc", "memory");
+    return m;
+}
+
 struct EmitTarget {  // positions >= capacity spill into the engine's scratch so that a buffer of exactly P records suffices
     arp_pair *out; unsigned long long capacity;
     arp_pair *scratch; unsigned long long scratch_cap;
@@ -264,6 +290,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
     uint32_t *ctr = task_ctr + (MODE * 8 + group) * kTaskCtrStride;
     uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); emit mode carries them across tasks
+    // LDS byte address of this wave's queue (for compact_round)
+    const uint32_t queue_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)w.queue);
     // The first task of every wave is static (its index among the group's waves): 6144 waves hitting the counters at
     // launch would be handed their first task one by one.  Later tasks come from the counter, which starts behind them.
     const uint32_t group_waves = ((gridDim.x - group + n_groups - 1u) / n_groups) * kWavesPerBlock;
@@ -353,22 +381,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
                     const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
                     if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);
                     // Compaction: one round per surviving test of the busiest lane; every round appends <= 64 entries
+                    // (mask bit 31 - lz <-> test u = lz - (32 - kBlock) <-> neighbour slot cs + wbase + u)
+                    const uint32_t nb_minus = cs + wbase - (32u - kBlock);
                     while (__any(mask != 0u)) {
-                        const bool has = mask != 0u;
-                        const uint32_t bit = 31u - (uint32_t)__clz((int)mask);
-                        const unsigned long long m = __ballot(has);
-                        if (has) {
-                            w.queue[qlen + mbcnt(m)] = make_uint2(a, cs + wbase + (kBlock - 1u - bit));
-                            mask &= ~(1u << bit);
-                        }
-                        qlen = __builtin_amdgcn_readfirstlane(qlen + (uint32_t)__popcll(m));
-                        if (qlen >= 64) {
-                            qlen -= 64;
+                        const uint32_t q0 = __builtin_amdgcn_readfirstlane(qlen);
+                        const unsigned long long m = compact_round(mask, a, nb_minus, queue_lds + 8u * q0);
+                        uint32_t q1 = q0 + (uint32_t)__popcll(m);
+                        if (q1 >= 64) {
+                            q1 -= 64;
                             wave_lds_fence();  // lanes read entries other lanes wrote
-                            const uint2 ent = w.queue[qlen + lane];
+                            const uint2 ent = w.queue[q1 + lane];
                             wave_lds_fence();
                             emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, true, base, emitted, tg, result, lane);
                         }
+                        qlen = q1;
                     }
                 }
             }
