@@ -127,7 +127,7 @@ def test_cys_without_cb_is_an_error_like_the_reference_panic(ctx):
     assert e.value.status == _lib.ARP_ERR_BAD_INPUT
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("ARP_FUZZ_CASES", "24"))))  # ARP_FUZZ_CASES=300 for a soak run
 def test_randomised_structures_and_parameters(ctx, case):
     """Random sizes, densities, chain groups, cutoffs and compensation factors: every combination goes through both emitters,
     the contacts-only filter and the oracle (covers the probe hand-off of the hot kernel on hydrogen-rich and hydrogen-free input)."""
