@@ -83,6 +83,30 @@ def _np_from(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dt, count=n).copy()
 
 
+class _PairsOwner:
+    """Keeps a library-allocated pair list alive for the numpy view over it; frees it with the last reference."""
+
+    def __init__(self, pairs):
+        self.pairs = pairs
+
+    def __del__(self):
+        if self.pairs is not None and lib is not None:
+            lib.arp_pairs_free(C.byref(self.pairs))
+            self.pairs = None
+
+
+def _adopt_pairs(out) -> np.ndarray:
+    """Zero-copy numpy view of an arp_pairs in host memory (copying a 460 MB list costs 200 ms of page faults)."""
+    n = int(out.n)
+    if not out.data or n == 0:
+        lib.arp_pairs_free(C.byref(out))
+        return np.zeros(0, dtype=PAIR_DTYPE)
+    owner = _PairsOwner(out)
+    buf = (C.c_char * (n * PAIR_DTYPE.itemsize)).from_address(out.data)
+    buf._owner = owner  # the ctypes buffer is the array's base: the owner lives exactly as long as the array (and its views)
+    return np.frombuffer(buf, dtype=PAIR_DTYPE, count=n)
+
+
 class Structure:
     """A parsed, filtered model: what `load_model` (utils.rs:51-63) returns in the reference."""
 
@@ -234,10 +258,7 @@ class Context:
         params = params or default_params()
         out = _lib.arp_pairs()
         _check(lib.arp_contacts_atomic(self._h, C.byref(atoms), C.byref(params), _lib.ARP_MEM_HOST, C.byref(out)))
-        try:
-            return _np_from(out.data, int(out.n), PAIR_DTYPE)
-        finally:
-            lib.arp_pairs_free(C.byref(out))
+        return _adopt_pairs(out)
 
     def enqueue(self, atoms: _lib.arp_atoms, params: _lib.arp_params, out_ptr: int, capacity: int):
         """Asynchronous, allocation-free form on device-resident data (arp_contacts_atomic_enqueue)."""
@@ -310,12 +331,16 @@ def atomic_contacts_batch(contexts, atoms_list, params: _lib.arp_params | None =
     outs = (_lib.arp_pairs * max(len(views), 1))()
     handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     st = lib.arp_contacts_atomic_batch(handles, len(contexts), arr, len(views), C.byref(params), outs)
-    try:
-        _check(st)
-        return [_np_from(outs[k].data, int(outs[k].n), PAIR_DTYPE) for k in range(len(views))]
-    finally:
+    if st != _lib.ARP_OK:
         for k in range(len(views)):
             lib.arp_pairs_free(C.byref(outs[k]))
+        _check(st)
+    result = []
+    for k in range(len(views)):  # every list becomes a zero-copy numpy view that frees it with its last reference
+        one = _lib.arp_pairs()
+        one.n, one.data, one.location = outs[k].n, outs[k].data, outs[k].location
+        result.append(_adopt_pairs(one))
+    return result
 
 
 _default_ctx: dict = {}

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include <numeric>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -94,6 +95,8 @@ struct arp_context {
         uint64_t bytes = 0;
     } st;
     arp_pair *out_buf = nullptr;            // reusable device output of the host-output path (grow-only)
+    char *bounce[2] = {nullptr, nullptr};   // pinned staging of large device -> host copies
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     uint64_t out_cap = 0;
     DevParams *h_params = nullptr;         // pinned
     unsigned long long *h_result = nullptr;  // pinned [2]
@@ -188,6 +191,7 @@ extern "C" void arp_context_destroy(arp_context *ctx) {
     free_workspace(ctx);
     free_staged(ctx);
     if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+    for (int k = 0; k < 2; k++) { if (ctx->bounce[k]) (void)hipHostFree(ctx->bounce[k]); if (ctx->bounce_ev[k]) (void)hipEventDestroy(ctx->bounce_ev[k]); }
     if (ctx->h_params) (void)hipHostFree(ctx->h_params);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->prof.created) for (int k = 0; k < Profiler::kMax; k++) { (void)hipEventDestroy(ctx->prof.ev0[k]); (void)hipEventDestroy(ctx->prof.ev1[k]); }
@@ -282,6 +286,65 @@ static arp_status flags_to_status(unsigned long long flags) {
     return ARP_OK;
 }
 
+// ---- device -> host of a large pair list ------------------------------------------------------------------------------
+// hipMemcpy into freshly malloc'd pageable memory runs at ~2 GB/s (page faults + the runtime's staging); a 460 MB list took
+// 230 ms.  Here the pages are populated by helper threads (MADV_POPULATE_WRITE, huge pages where the kernel grants them)
+// while the list streams through two pinned 16 MB bounce buffers.
+static arp_pair *download_pairs(arp_context *ctx, const arp_pair *dev, unsigned long long total, arp_status *status) {
+    const size_t bytes = (size_t)total * sizeof(arp_pair);
+    *status = ARP_OK;
+    constexpr size_t kBounce = 16u << 20;
+    if (bytes < 4 * kBounce) {
+        arp_pair *host = (arp_pair *)malloc(bytes);
+        if (!host) { set_error("out of host memory"); *status = ARP_ERR_OOM; return nullptr; }
+        hipError_t e = hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(host); set_error("HIP error %d copying pairs to the host", (int)e); *status = ARP_ERR_HIP; return nullptr; }
+        return host;
+    }
+    const size_t kHuge = 2u << 20;
+    char *host = (char *)aligned_alloc(kHuge, (bytes + kHuge - 1) / kHuge * kHuge);
+    if (!host) { set_error("out of host memory"); *status = ARP_ERR_OOM; return nullptr; }
+#ifdef MADV_HUGEPAGE
+    (void)madvise(host, bytes, MADV_HUGEPAGE);
+#endif
+    const int n_pop = 4;
+    std::vector<std::thread> pop;
+    for (int t = 0; t < n_pop; t++)
+        pop.emplace_back([=]() {
+            const size_t lo = bytes / n_pop * t / 4096 * 4096, hi = (t + 1 == n_pop) ? bytes : bytes / n_pop * (t + 1) / 4096 * 4096;
+#ifdef MADV_POPULATE_WRITE
+            if (madvise(host + lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+#endif
+            (void)lo; (void)hi;  // older kernels: the copy below faults the pages in
+        });
+    if (!ctx->bounce[0]) {
+        for (int k = 0; k < 2; k++) {
+            if (hipHostMalloc((void **)&ctx->bounce[k], kBounce, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->bounce_ev[k], hipEventDisableTiming) != hipSuccess) {
+                for (auto &t : pop) t.join();
+                free(host); set_error("cannot allocate the pinned bounce buffers"); *status = ARP_ERR_HIP; return nullptr;
+            }
+        }
+    }
+    hipError_t e = hipSuccess;
+    const size_t n_chunks = (bytes + kBounce - 1) / kBounce;
+    for (size_t c = 0; c <= n_chunks && e == hipSuccess; c++) {
+        if (c < n_chunks) {
+            const size_t off = c * kBounce, len = std::min(kBounce, bytes - off);
+            e = hipMemcpyAsync(ctx->bounce[c & 1], (const char *)dev + off, len, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->bounce_ev[c & 1], ctx->stream);
+        }
+        if (c > 0 && e == hipSuccess) {  // drain the previous chunk while this one is in flight
+            const size_t off = (c - 1) * kBounce, len = std::min(kBounce, bytes - off);
+            e = hipEventSynchronize(ctx->bounce_ev[(c - 1) & 1]);
+            if (e == hipSuccess) memcpy(host + off, ctx->bounce[(c - 1) & 1], len);
+        }
+    }
+    for (auto &t : pop) t.join();
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); free(host); set_error("HIP error %d copying pairs to the host", (int)e); *status = ARP_ERR_HIP; return nullptr; }
+    return (arp_pair *)host;
+}
+
 // ---- the hot path ----------------------------------------------------------------------------------------------
 extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, arp_pair *out,
                                                   uint64_t capacity) {
@@ -367,10 +430,8 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
             want = total + total / 8;
         }
         if (total == 0) return ARP_OK;
-        arp_pair *host = (arp_pair *)malloc(total * sizeof(arp_pair));
-        if (!host) { set_error("out of host memory"); return ARP_ERR_OOM; }
-        hipError_t e = hipMemcpy(host, ctx->out_buf, total * sizeof(arp_pair), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { free(host); set_error("HIP error %d copying pairs to the host", (int)e); return ARP_ERR_HIP; }
+        arp_pair *host = download_pairs(ctx, ctx->out_buf, total, &s);
+        if (!host) return s;
         out->data = host; out->n = total;
         return ARP_OK;
     }
@@ -400,11 +461,9 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
         out->data = dev; out->n = total;
         return ARP_OK;
     }
-    arp_pair *host = (arp_pair *)malloc(total * sizeof(arp_pair));
-    if (!host) { (void)hipFree(dev); set_error("out of host memory"); return ARP_ERR_OOM; }
-    e = hipMemcpy(host, dev, total * sizeof(arp_pair), hipMemcpyDeviceToHost);
+    arp_pair *host = download_pairs(ctx, dev, total, &s);
     (void)hipFree(dev);
-    if (e != hipSuccess) { free(host); set_error("HIP error %d copying pairs to the host", (int)e); return ARP_ERR_HIP; }
+    if (!host) return s;
     out->data = host; out->n = total;
     return ARP_OK;
 }
@@ -569,7 +628,10 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
             };
             Pack pk;
             for (int32_t k : queue[d]) {
-                const Extent e = measure(atoms[k]);
+                // Packing pays when the launch overhead dominates, i.e. for the small contacts-only lists; full candidate lists are
+                // bound by the copy to the host, which a pack would only add a second (splitting) pass to.
+                Extent e = measure(atoms[k]);
+                if (!(params->flags & ARP_FLAG_CONTACTS_ONLY)) e.packable = false;
                 arp_status s = ARP_OK;
                 if (!e.packable) {
                     if ((s = flush(pk)) != ARP_OK || (s = run_single(k)) != ARP_OK) return fail(s);

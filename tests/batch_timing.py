@@ -33,4 +33,4 @@ for only in (False, True):
         assert np.array_equal(canon(packed[k]), canon(singles[k]))
     print(f"{n_structs} structures, {atoms} atoms, {pairs} pairs out, contacts_only={only} (host buffers in, host pairs out)")
     print(f"  one call per structure : {t_single * 1e3:9.1f} ms  {t_single / n_structs * 1e6:7.0f} us/structure  {atoms / t_single:.3e} atoms/s")
-    print(f"  packed batch           : {t_pack * 1e3:9.1f} ms  {t_pack / n_structs * 1e6:7.0f} us/structure  {atoms / t_pack:.3e} atoms/s")
+    print(f"  batch call (packs if contacts-only): {t_pack * 1e3:9.1f} ms  {t_pack / n_structs * 1e6:7.0f} us/structure  {atoms / t_pack:.3e} atoms/s")

@@ -363,14 +363,18 @@ def test_packed_batch_equals_single_calls(ctx):
     views = [s.view("/") for s in structs]
     singles = [ctx.atomic_contacts(v) for v in views]
     assert len(singles[-1]) == 0 and len(singles[0]) == 9128
-    for prm in (aa.default_params(), aa.default_params(deterministic=True)):
-        got = aa.atomic_contacts_batch([ctx], views, prm)
-        assert len(got) == len(views)
+    # packs are formed for contacts-only lists (full lists are copy-bound and go one structure at a time)
+    for det in (False, True):
+        got = aa.atomic_contacts_batch([ctx], views, aa.default_params(deterministic=det))
+        packed = aa.atomic_contacts_batch([ctx], views, aa.default_params(deterministic=det, contacts_only=True))
+        assert len(got) == len(packed) == len(views)
         for k in range(len(views)):
             assert np.array_equal(canon(got[k]), canon(singles[k])), k
+            assert np.array_equal(canon(packed[k]), canon(singles[k][singles[k]["kind"] != 0])), k
     # the oracle on one packed member, to pin the whole chain
-    orc = ob.Structure.load(str(synth.DATA / "6bft.pdb"))
-    assert_pairs_equal(got[1], orc.atomic_contacts(), "6bft from a pack")
+    want = ob.Structure.load(str(synth.DATA / "6bft.pdb")).atomic_contacts()
+    assert_pairs_equal(got[1], want, "6bft from a batch")
+    assert_pairs_equal(packed[1], want[want["kind"] != 0], "6bft from a pack")
 
 
 @pytest.mark.parametrize("source", ["6bft", "stress", "s1"])
@@ -422,10 +426,12 @@ def test_packed_batch_reports_the_failing_structure(ctx):
     bad["resi"][:] = [1, 1, 5, 5]
     bad["x"][:] = [0.0, 1.5, 2.05, 3.5]; bad["y"][:] = 0.0; bad["z"][:] = 0.0
     structs = [aa.Structure.from_records(r) for r in (ok, bad, ok)]
-    with pytest.raises(aa.ArpeggiaError) as e:
-        aa.atomic_contacts_batch([ctx], [s.view("/") for s in structs])
-    assert e.value.status == _lib.ARP_ERR_BAD_INPUT and "CB" in str(e.value)
-    assert len(aa.atomic_contacts_batch([ctx], [structs[0].view("/"), structs[2].view("/")])) == 2
+    for only in (True, False):  # packed (contacts-only) and one-by-one
+        prm = aa.default_params(contacts_only=only)
+        with pytest.raises(aa.ArpeggiaError) as e:
+            aa.atomic_contacts_batch([ctx], [s.view("/") for s in structs], prm)
+        assert e.value.status == _lib.ARP_ERR_BAD_INPUT and "CB" in str(e.value)
+        assert len(aa.atomic_contacts_batch([ctx], [structs[0].view("/"), structs[2].view("/")], prm)) == 2
 
 
 # ---------------------------------------------------------------------------------------------- the table (get_contacts)
