@@ -155,7 +155,8 @@ arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs);
 
 /* Batch of independent structures sharded over devices (no collective).  ctxs[d] is a context on
  * device d; structure k goes to a device by longest-processing-time-first on its atom count; one host thread
- * per device.  outs[k] is filled like arp_contacts_atomic (host memory). */
+ * per device; with ARP_FLAG_CONTACTS_ONLY small structures of a device's share are packed into shared launches.
+ * outs[k] is filled like arp_contacts_atomic (host memory). */
 arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms,
                                      int32_t n_structures, const arp_params *params, arp_pairs *outs);
 
