@@ -104,6 +104,7 @@ struct PlaneEntry {
     int32_t model_serial; std::string chain; int32_t resi; std::string icode, altloc, resn;
     Plane plane;
     bool has_ord = false; uint32_t ord = 0;   // res2idx[(model, chain, resi, icode, altloc, resn)]
+    uint32_t res = 0, alt_k = 0;              // the residue (and which of its conformer altlocs) the plane was last written from
     uint16_t chain_rank = 0; bool in_l = false, in_r = false;
 };
 // (model serial, chain id, resi, icode, altloc, resn) with the names packed into integers (ids are <= 7 / 3 characters, the
@@ -136,13 +137,17 @@ static PlaneKey plane_key(int32_t model, const char *chain, int32_t resi, const 
     return PlaneKey{model, resi, (uint32_t)pack_name(icode, 4), (uint32_t)pack_name(altloc, 4), pack_name(chain, 8), pack_name(resn, 8)};
 }
 
-static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEntry> *out, PlaneIndex *index) {
+// `first_of_res` (single-model structures only, else left empty): entry of (residue r, its altloc k) = first_of_res[r] + k, -1 if r has
+// no plane -- one model holds one residue per (chain, resi, icode), so no key can be written twice and no keyed lookup is needed.
+static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEntry> *out, PlaneIndex *index, std::vector<int64_t> *first_of_res) {
     std::vector<int32_t> serials;
     for (const ChainInfo &c : s.chains) if (std::find(serials.begin(), serials.end(), c.model_serial) == serials.end()) serials.push_back(c.model_serial);
     // res2idx: (model serial, chain, resi, icode) -> residue
     // With ONE model serial a plane entry can only resolve to the residue it was fitted from (the hierarchy holds one residue
     // per (chain, resi, icode)); the keyed lookup below is needed for multi-model files only.
     const bool one_model = serials.size() <= 1;
+    const bool direct = s.chains.empty() || s.chains.back().model_idx == 0;  // a single model in the file
+    if (direct) first_of_res->assign(s.residues.size(), -1);
     std::unordered_map<PlaneKey, uint32_t, PlaneKeyHash> res_of;
     if (!one_model) {
         res_of.reserve(s.residues.size() * 2);
@@ -151,7 +156,7 @@ static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEn
             res_of[plane_key(s.chains[ri.chain].model_serial, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), "", "")] = r;
         }
     }
-    index->reserve(s.residues.size() * 2);
+    if (!direct) index->reserve(s.residues.size() * 2);
     // complex.rs:447-449 / 489-492: for EVERY model serial, ALL chains of ALL models are visited; later inserts overwrite
     // the plane of a residue does not depend on the model serial it is filed under: fit once (in parallel), file per serial
     std::vector<Plane> fitted(s.residues.size());
@@ -172,13 +177,20 @@ static void build_planes(const arp_structure &s, bool rings, std::vector<PlaneEn
             const ResidueInfo &ri = s.residues[r];
             if (!has_plane[r]) continue;
             const Plane &pl = fitted[r];
-            for (const std::string &alt : ri.altlocs) {
-                const PlaneKey key = plane_key(m, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), alt.c_str(), ri.name.c_str());
-                auto it = index->find(key);
-                if (it == index->end()) { it = index->emplace(key, out->size()).first; out->push_back(PlaneEntry{}); }
-                PlaneEntry &e = (*out)[it->second];
+            if (direct) (*first_of_res)[r] = (int64_t)out->size();
+            for (uint32_t k = 0; k < ri.altlocs.size(); k++) {
+                const std::string &alt = ri.altlocs[k];
+                size_t slot;
+                if (direct) { slot = out->size(); out->push_back(PlaneEntry{}); }
+                else {
+                    const PlaneKey key = plane_key(m, s.chains[ri.chain].id.c_str(), ri.resi, ri.icode.c_str(), alt.c_str(), ri.name.c_str());
+                    auto it = index->find(key);
+                    if (it == index->end()) { it = index->emplace(key, out->size()).first; out->push_back(PlaneEntry{}); }
+                    slot = it->second;
+                }
+                PlaneEntry &e = (*out)[slot];
                 e.model_serial = m; e.chain = s.chains[ri.chain].id; e.resi = ri.resi; e.icode = ri.icode; e.altloc = alt; e.resn = ri.name;
-                e.plane = pl;
+                e.plane = pl; e.res = r; e.alt_k = k;
                 if (one_model) { e.has_ord = true; e.ord = ri.ord; }
             }
         }
@@ -250,9 +262,11 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     if (st != ARP_OK) return st;
     std::vector<PlaneEntry> rings, scp;
     PlaneIndex ring_idx, sc_idx;
-    build_planes(*s, true, &rings, &ring_idx);
+    std::vector<int64_t> ring_first, sc_first;  // single-model structures: direct (residue, altloc) -> entry tables
+    build_planes(*s, true, &rings, &ring_idx, &ring_first);
     if (rings.empty()) { set_error("Error building ring positions"); return ARP_ERR_NO_RINGS; }  // complex.rs:50
-    build_planes(*s, false, &scp, &sc_idx);
+    build_planes(*s, false, &scp, &sc_idx, &sc_first);
+    const bool direct = !sc_first.empty() || s->residues.empty();
     std::unordered_map<std::string, uint16_t> rank;
     for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
     std::vector<char> chain_l(s->chain_ids.size(), 0), chain_r(s->chain_ids.size(), 0);
@@ -288,6 +302,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
                 const uint32_t a0 = ri.atoms[0];
                 plane_of_alt.assign(ri.altlocs.size(), -1);
                 for (size_t k = 0; k < ri.altlocs.size(); k++) {
+                    if (direct) { if (sc_first[r] >= 0) plane_of_alt[k] = sc_first[r] + (int64_t)k; continue; }
                     auto f = sc_idx.find(plane_key(s->model_serial[a0], s->chain.at(a0), s->resi[a0], s->icode.at(a0), ri.altlocs[k].c_str(), s->res_resn.at(a0)));
                     if (f != sc_idx.end()) plane_of_alt[k] = (int64_t)f->second;
                 }
@@ -310,8 +325,11 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
         put(e.chain, 8, r.chain); put(e.resn, 8, r.resn); put(e.atomn, 8, "Ring"); put(e.insertion, 4, r.icode); put(e.altloc, 4, r.altloc);
         e.resi = r.resi; e.atomi = 0; e.atom = -1;
         e.chain_rank = r.chain_rank;
-        auto f = sc_idx.find(plane_key(r.model_serial, r.chain.c_str(), r.resi, r.icode.c_str(), r.altloc.c_str(), r.resn.c_str()));
-        e.sc_plane = f == sc_idx.end() ? -1 : (int64_t)f->second;
+        if (direct) e.sc_plane = sc_first[r.res] >= 0 ? sc_first[r.res] + (int64_t)r.alt_k : -1;  // same residue, same conformer altloc
+        else {
+            auto f = sc_idx.find(plane_key(r.model_serial, r.chain.c_str(), r.resi, r.icode.c_str(), r.altloc.c_str(), r.resn.c_str()));
+            e.sc_plane = f == sc_idx.end() ? -1 : (int64_t)f->second;
+        }
         return e;
     };
     // one row per set bit: a prefix count gives every worker its own output range (rows keep the pair order)
