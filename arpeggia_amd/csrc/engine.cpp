@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <numeric>
 #include <sys/mman.h>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -309,7 +310,7 @@ static arp_pair *download_pairs(arp_context *ctx, const arp_pair *dev, unsigned 
 #endif
     const int n_pop = 4;
     std::vector<std::thread> pop;
-    for (int t = 0; t < n_pop; t++)
+    for (int t = 0; t < n_pop; t++) try {
         pop.emplace_back([=]() {
             const size_t lo = bytes / n_pop * t / 4096 * 4096, hi = (t + 1 == n_pop) ? bytes : bytes / n_pop * (t + 1) / 4096 * 4096;
 #ifdef MADV_POPULATE_WRITE
@@ -317,6 +318,7 @@ static arp_pair *download_pairs(arp_context *ctx, const arp_pair *dev, unsigned 
 #endif
             (void)lo; (void)hi;  // older kernels: the copy below faults the pages in
         });
+    } catch (const std::system_error &) { break; }  // no helper thread: the copy faults the pages in itself
     if (!ctx->bounce[0]) {
         for (int k = 0; k < 2; k++) {
             if (hipHostMalloc((void **)&ctx->bounce[k], kBounce, hipHostMallocDefault) != hipSuccess ||
