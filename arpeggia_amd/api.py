@@ -361,9 +361,12 @@ def get_contacts(structure: Structure, groups: str = "/", vdw_comp: float = 0.1,
     """`arpeggia::get_contacts(&pdb, groups, vdw_comp, dist_cutoff) -> DataFrame` (mod.rs:61).
 
     The table crosses into Python as one Arrow record batch (arp_table_export_arrow): no per-row Python work."""
+    return _table(_context(device), structure, groups, vdw_comp, dist_cutoff)
+
+
+def _table(ctx: "Context", structure: Structure, groups: str, vdw_comp: float, dist_cutoff: float):
     import pyarrow as pa
 
-    ctx = _context(device)
     t = C.c_void_p()
     _check(lib.arp_get_contacts(ctx._h, structure._h, groups.encode(), vdw_comp, dist_cutoff, C.byref(t)))
     try:
@@ -418,3 +421,33 @@ def contacts(input_file: str, groups: str = "/", vdw_comp: float = 0.1, dist_cut
     lib.arp_set_num_threads(int(num_threads))  # host threads of the table path (the reference's rayon pool); 0 = all
     s = Structure.load(input_file, ignore_zero_occupancy)
     return get_contacts(s, groups, vdw_comp, dist_cutoff)
+
+
+def contacts_batch(input_files, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5, ignore_zero_occupancy: bool = False,
+                   num_workers: int = 8, devices=None) -> list:
+    """`contacts()` over many files: parsing, GPU pairs and table assembly of different files overlap on `num_workers` host threads
+    (the C library releases the GIL), each with its own context; files are dealt round-robin over `devices` (default: all visible
+    gfx950 devices).  Results come back in input order.  This is the file-level form of BASELINE config 5 (a batch of independent
+    structures): on real files the parse and the host table, not the GPU, set the pace, and they scale with the workers."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    files = [str(f) for f in input_files]
+    devs = list(devices) if devices is not None else list(range(max(device_count(), 1)))
+    local = threading.local()
+
+    def one(job):
+        k, path = job
+        dev = devs[k % len(devs)]
+        ctxs = getattr(local, "ctxs", None)
+        if ctxs is None:
+            ctxs = local.ctxs = {}
+        if dev not in ctxs:
+            ctxs[dev] = Context(dev)
+        s = Structure.load(path, ignore_zero_occupancy)
+        return _table(ctxs[dev], s, groups, vdw_comp, dist_cutoff)
+
+    if not files:
+        return []
+    with ThreadPoolExecutor(max_workers=max(1, min(int(num_workers), len(files)))) as pool:
+        return list(pool.map(one, enumerate(files)))

@@ -558,6 +558,23 @@ def test_cli_contacts_end_to_end(ctx, tmp_path):
     assert main(["contacts", "-i", str(tmp_path / "missing.pdb"), "-o", str(tmp_path / "out")]) == 1
 
 
+def test_contacts_batch_over_files(ctx, tmp_path):
+    # many files through worker threads == the same files one by one, in input order
+    files = [str(synth.DATA / "1ubq.pdb"), str(synth.DATA / "6bft.pdb")] * 6
+    p = tmp_path / "stress.pdb"
+    synth.write_pdb(synth.gen_stress(n_res=120, seed=91, n_chains=2), p)
+    files.append(str(p))
+    one_by_one = [aa.contacts(f) for f in files[:2]] + [aa.contacts(files[-1])]
+    got = aa.contacts_batch(files, num_workers=4)
+    assert len(got) == len(files)
+    rows = lambda t: t.num_rows if hasattr(t, "num_rows") else t.height
+    assert [rows(t) for t in got[:2]] == [532, 7236]
+    for k, t in enumerate(got):
+        ref = one_by_one[2] if k == len(files) - 1 else one_by_one[k % 2]
+        assert t.equals(ref), k
+    assert aa.contacts_batch([]) == []
+
+
 def test_no_ring_structure_is_an_error(ctx):
     # complex.rs:50,480-482: panics when the model has no HIS/PHE/TYR/TRP ring
     prod, orc = _both_from(_mini([[0, 0, 0], [3, 0, 0], [0, 3, 0]]))
