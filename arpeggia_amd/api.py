@@ -357,18 +357,20 @@ def load_model(input_file, ignore_zero_occupancy: bool = False) -> Structure:
     return Structure.load(input_file, ignore_zero_occupancy)
 
 
-def get_contacts(structure: Structure, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5, device: int = 0):
+def get_contacts(structure: Structure, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5, device: int = 0,
+                 num_threads: int = -1):
     """`arpeggia::get_contacts(&pdb, groups, vdw_comp, dist_cutoff) -> DataFrame` (mod.rs:61).
 
-    The table crosses into Python as one Arrow record batch (arp_table_export_arrow): no per-row Python work."""
-    return _table(_context(device), structure, groups, vdw_comp, dist_cutoff)
+    The table crosses into Python as one Arrow record batch (arp_table_export_arrow): no per-row Python work.
+    `num_threads`: host workers of THIS call (0 = all cores, < 0 = the process-wide default of arp_set_num_threads)."""
+    return _table(_context(device), structure, groups, vdw_comp, dist_cutoff, num_threads)
 
 
-def _table(ctx: "Context", structure: Structure, groups: str, vdw_comp: float, dist_cutoff: float):
+def _table(ctx: "Context", structure: Structure, groups: str, vdw_comp: float, dist_cutoff: float, num_threads: int = -1):
     import pyarrow as pa
 
     t = C.c_void_p()
-    _check(lib.arp_get_contacts(ctx._h, structure._h, groups.encode(), vdw_comp, dist_cutoff, C.byref(t)))
+    _check(lib.arp_get_contacts_mt(ctx._h, structure._h, groups.encode(), vdw_comp, dist_cutoff, int(num_threads), C.byref(t)))
     try:
         arr, sch = _lib.ArrowArray(), _lib.ArrowSchema()
         _check(lib.arp_table_export_arrow(t, C.byref(arr), C.byref(sch)))
@@ -383,44 +385,16 @@ def _table(ctx: "Context", structure: Structure, groups: str, vdw_comp: float, d
         return table
 
 
-def _to_frame(cols: dict):
-    import pyarrow as pa
-
-    names = np.array(_lib.INTERACTIONS)
-    arrays, fields = [], []
-    valid = cols["sc_valid"]
-    for name, kind in TABLE_COLUMNS:
-        v = cols[name]
-        if name == "interaction":
-            arr = pa.array(names[v], type=pa.string()) if len(v) else pa.array([], type=pa.string())
-        elif kind == "str":
-            arr = pa.array(np.char.decode(v, "ascii") if len(v) else [], type=pa.string())
-        elif name.startswith("sc_"):
-            arr = pa.array(v, type=pa.float32(), mask=~valid)  # null where either residue has no side-chain plane
-        else:
-            arr = pa.array(v, type={"u4": pa.uint32(), "i4": pa.int32(), "f4": pa.float32()}[kind])
-        arrays.append(arr)
-        fields.append(name)
-    table = pa.table(arrays, names=fields)
-    try:  # the reference returns a polars.DataFrame (python.rs:55); same Arrow buffers when polars is installed
-        import polars as pl
-
-        return pl.from_arrow(table)
-    except ImportError:
-        return table
-
-
 def contacts(input_file: str, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5,
              ignore_zero_occupancy: bool = False, num_threads: int = 1):
     """Drop-in for `arpeggia.contacts` (src/python.rs:31-56): same keywords and defaults, 20-column table.
 
-    Returns a polars.DataFrame when polars is importable, else the identical pyarrow.Table.  `num_threads` is accepted
-    for signature compatibility (the reference sizes a rayon pool with it, utils.rs:8-30); the search and classification
-    run on the GPU regardless.
+    Returns a polars.DataFrame when polars is importable, else the identical pyarrow.Table.  `num_threads` sizes the host
+    workers of this call only (the reference builds a scoped rayon pool per call, utils.rs:8-30; 0 = all cores); no
+    process-wide state is touched, and the search and classification run on the GPU regardless.
     """
-    lib.arp_set_num_threads(int(num_threads))  # host threads of the table path (the reference's rayon pool); 0 = all
     s = Structure.load(input_file, ignore_zero_occupancy)
-    return get_contacts(s, groups, vdw_comp, dist_cutoff)
+    return get_contacts(s, groups, vdw_comp, dist_cutoff, num_threads=int(num_threads))
 
 
 def contacts_batch(input_files, groups: str = "/", vdw_comp: float = 0.1, dist_cutoff: float = 6.5, ignore_zero_occupancy: bool = False,

@@ -33,9 +33,9 @@ struct GridParams {
     uint32_t ncells;      // nx * ny * nzt
     uint32_t n_heavy;     // atoms in the grid (non-H)
     uint32_t n_tasks;     // ceil(n_heavy / 64): one wave-task per 64 consecutive slots
-    uint32_t bad;         // non-finite coordinate seen
+    uint32_t bad;         // bit 0: non-finite coordinate seen, bit 1: model ids too sparse for the workspace
     float prefilter_margin;
-    uint32_t pad;
+    uint32_t all_both;    // every heavy atom is in the ligand AND the receptor set (groups "/"): orient() takes its short form
     double mx, my, mz;    // box midpoint: the f32 prefilter records are relative to it (halves their magnitude)
     double r2m;           // prefilter threshold on d^2 in f64: r2 + storage margin + dot-form margin
 };
@@ -50,12 +50,17 @@ struct DevAtoms {
     uint32_t n_res;
 };
 
-// Exact-phase record of one heavy atom, 48 B = three 16-byte loads.
+// Exact-phase record of one heavy atom, 48 B = three 16-byte parts.  The hot kernels read parts 0 and 1 whole and the first
+// half of part 2; `attr` (the caller's word + the residue-has-hydrogens bit) is only read by the deferred probe passes.
+//   pw = pair word, built when the atom is placed (grid.inl make_pair_word): element class in bits 0-3, the class bits the
+//   pair rules combine as two bytes P (bits 8-14) and Q (bits 16-22) such that (Pa & Qb) | (Pb & Qa) has one bit per pair
+//   predicate, LIGAND / RECEPTOR in bits 24 / 25, residue-has-hydrogens in bit 31.
 struct __attribute__((aligned(16))) Fat {
-    double x, y, z;
-    uint32_t attr, res_ord, crm /* chain_rank | model << 16 */, orig /* index into the caller's arrays */;
-    uint32_t cell, spare;  // cell id of the slot (a task's home lanes derive their windows from it); fills the 16-byte tail
+    double x, y;
+    double z; uint32_t pw, res_ord;
+    uint32_t crm /* chain_rank | model << 16 */, orig /* index into the caller's arrays */, cell /* cell id of the slot */, attr;
 };
+constexpr uint32_t kPwLigand = 1u << 24, kPwReceptor = 1u << 25, kPwResHasH = 1u << 31;
 
 // Cell-sorted copy of the heavy atoms (slot order: x-major cells, atoms of a cell in ascending input index).
 struct Sorted {
@@ -111,7 +116,7 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
 void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out, bool contacts_only);
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof,
                          bool contacts_only);
-void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
+void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only);
 unsigned long long emit_scratch_records();
 
 }  // namespace arp

@@ -105,6 +105,9 @@ struct arp_context {
     bool have_params = false;
     uint64_t last_capacity = 0;
     bool pending = false;
+    uint32_t defer_scale = 1;              // the deferred-probe list is sized defer_scale x the default; grown on overflow
+    arp_atoms last_atoms{};                // the enqueued call, kept so that arp_contacts_atomic_result can re-run it after growing a list
+    arp_pair *last_out = nullptr;
     Profiler prof;
 };
 
@@ -144,12 +147,26 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.perm, cap); A(w.slot_cell, cap);
     A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
-    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 4);  // scan_tmp*: >= kScanBlocks + 1
+    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 32);  // result[8..31]: cycle stamps of diagnostic builds (ARP_STAMP)  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
-    w.defer_cap = std::max<uint64_t>(16 * cap, 1u << 20) + (1u << 20); A(w.defer_list, w.defer_cap);  // + one partly used 512-entry chunk per block
+    w.defer_cap = (uint64_t)ctx->defer_scale * std::max<uint64_t>(16 * cap, 1u << 20) + (1u << 20);  // + one partly used 512-entry chunk per block
+    if (const char *dbg = getenv("ARP_DEBUG_DEFER_ENTRIES")) {  // tests: a tiny list, so that the grow-and-repeat path runs
+        const long v = atol(dbg);
+        if (v > 0) w.defer_cap = (uint64_t)ctx->defer_scale * (uint64_t)v;
+    }
+    A(w.defer_list, w.defer_cap);
 #undef A
     w.n_cap = (uint32_t)cap;
     w.ncells_cap = (uint32_t)ccap;
+    {   // Every pointer a kernel may dereference must exist before the first launch.  (Round 1 recorded one GPU fault "on address
+        // (nil)": an intermediate build launched k_bounds with the then-new `partials` member not yet allocated here.  A member
+        // added to Workspace without its allocation now fails this check on the host instead of faulting on the device.)
+        const void *members[] = {w.partials, w.tickets, w.grid, w.params, w.cell_of_atom, w.rank_of_atom, w.cell_count, w.cell_start, w.perm, w.slot_cell,
+                                 w.sorted.rec, w.sorted.fat, w.task_count, w.task_base, w.scan_tmp, w.scan_tmp64, w.result, w.hole_list, w.scratch,
+                                 w.task_ctr, w.defer_list};
+        for (const void *m : members)
+            if (!m) { free_workspace(ctx); set_error("internal error: a workspace member was not allocated"); return ARP_ERR_HIP; }
+    }
     // self-cleaning state: the kernels leave these zeroed for the next call
     HIP_TRY(hipMemsetAsync(w.cell_count, 0, (ccap + 1) * sizeof(uint32_t), ctx->stream));
     HIP_TRY(hipMemsetAsync(w.tickets, 0, 4 * sizeof(uint32_t), ctx->stream));
@@ -279,11 +296,13 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
     return ARP_OK;
 }
 
+constexpr arp_status kRetryDefer = -1;  // internal: never crosses the C ABI
 static arp_status flags_to_status(unsigned long long flags) {
     if (flags & 4ull) { set_error("non-finite atom coordinate"); return ARP_ERR_BAD_INPUT; }
+    if (flags & 64ull) { set_error("model ordinals must be dense: the largest model id exceeds what the workspace of this input holds (model ids count 0, 1, 2, ...)"); return ARP_ERR_BAD_INPUT; }
     if (flags & 16ull) { set_error("internal error: inconsistent hole plan in k_fixup"); return ARP_ERR_HIP; }
-    if (flags & 8ull) { set_error("deferred-probe list overflow (more than 8 probe candidates per atom); rerun with ARP_FLAG_DETERMINISTIC | ARP_FLAG_CONTACTS_ONLY"); return ARP_ERR_CAPACITY; }
     if (flags & 2ull) { set_error("CYS SG..SG covalent pair whose residue has no CB (the reference panics in is_disulfide, vdw.rs:58)"); return ARP_ERR_BAD_INPUT; }
+    if (flags & 8ull) return kRetryDefer;  // the deferred-probe list overflowed: the caller grows it and repeats the pass
     return ARP_OK;
 }
 
@@ -319,14 +338,26 @@ static arp_pair *download_pairs(arp_context *ctx, const arp_pair *dev, unsigned 
             (void)lo; (void)hi;  // older kernels: the copy below faults the pages in
         });
     } catch (const std::system_error &) { break; }  // no helper thread: the copy faults the pages in itself
-    if (!ctx->bounce[0]) {
-        for (int k = 0; k < 2; k++) {
-            if (hipHostMalloc((void **)&ctx->bounce[k], kBounce, hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&ctx->bounce_ev[k], hipEventDisableTiming) != hipSuccess) {
-                for (auto &t : pop) t.join();
-                free(host); set_error("cannot allocate the pinned bounce buffers"); *status = ARP_ERR_HIP; return nullptr;
+    bool have_bounce = ctx->bounce[0] && ctx->bounce[1] && ctx->bounce_ev[0] && ctx->bounce_ev[1];
+    if (!have_bounce) {  // all four handles or none: a half-built set would hand null buffers to later calls
+        have_bounce = true;
+        for (int k = 0; k < 2 && have_bounce; k++)
+            have_bounce = hipHostMalloc((void **)&ctx->bounce[k], kBounce, hipHostMallocDefault) == hipSuccess &&
+                          hipEventCreateWithFlags(&ctx->bounce_ev[k], hipEventDisableTiming) == hipSuccess;
+        if (!have_bounce) {
+            (void)hipGetLastError();
+            for (int k = 0; k < 2; k++) {
+                if (ctx->bounce[k]) (void)hipHostFree(ctx->bounce[k]);
+                if (ctx->bounce_ev[k]) (void)hipEventDestroy(ctx->bounce_ev[k]);
+                ctx->bounce[k] = nullptr; ctx->bounce_ev[k] = nullptr;
             }
         }
+    }
+    if (!have_bounce) {  // no pinned staging: the plain copy still works, only slower
+        const hipError_t e = hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
+        for (auto &t : pop) t.join();
+        if (e != hipSuccess) { free(host); set_error("HIP error %d copying pairs to the host", (int)e); *status = ARP_ERR_HIP; return nullptr; }
+        return (arp_pair *)host;
     }
     hipError_t e = hipSuccess;
     const size_t n_chunks = (bytes + kBounce - 1) / kBounce;
@@ -345,6 +376,16 @@ static arp_pair *download_pairs(arp_context *ctx, const arp_pair *dev, unsigned 
     for (auto &t : pop) t.join();
     if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); free(host); set_error("HIP error %d copying pairs to the host", (int)e); *status = ARP_ERR_HIP; return nullptr; }
     return (arp_pair *)host;
+}
+
+// The deferred-probe list (candidates whose rules need a hydrogen / disulfide probe) is sized for 16 candidates per atom; a
+// denser input overflows it (status bit 8).  Like the pair buffer, it is then grown and the pass repeated.
+static arp_status grow_defer_list(arp_context *ctx, uint64_t n) {
+    if (ctx->defer_scale >= 64) { set_error("deferred-probe list overflow after growing it 64-fold"); return ARP_ERR_CAPACITY; }
+    ctx->defer_scale *= 4;
+    (void)hipStreamSynchronize(ctx->stream);
+    free_workspace(ctx);
+    return ensure_workspace(ctx, n);
 }
 
 // ---- the hot path ----------------------------------------------------------------------------------------------
@@ -368,11 +409,12 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
         launch_count(d, ctx->ws, ctx->stream, prof, capacity, true, only);
         launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof, only);
     } else {
-        launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof);
+        launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     ctx->last_capacity = capacity;
+    ctx->last_atoms = *atoms; ctx->last_out = out;  // (device pointers: the caller keeps them alive until arp_contacts_atomic_result)
     ctx->pending = true;
     return ARP_OK;
 }
@@ -381,10 +423,27 @@ extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_p
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
     if (!ctx->pending) { set_error("no enqueued call"); return ARP_ERR_BAD_INPUT; }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->pending = false;
-    if (n_pairs) *n_pairs = ctx->h_result[0];
-    if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
+    for (;;) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->pending = false;
+#ifdef ARP_STAMP   // diagnostic build: per-segment wave cycles of the emit kernel (summed over waves), see pairs_lds.inl
+        if (getenv("ARP_STAMP_PRINT")) {
+            unsigned long long st[24];
+            if (hipMemcpy(st, ctx->ws.result + 8, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+                static const char *nm[] = {"total", "prologue", "stage", "prefilter", "compact", "exact_full", "exact_part", "handout", "n_full", "n_part", "n_chunks", "n_tasks"};
+                for (int k = 0; k < 12; k++) fprintf(stderr, "stamp %-10s %14llu%s", nm[k], st[k], k % 4 == 3 ? "\n" : "  ");
+            }
+        }
+#endif
+        if (n_pairs) *n_pairs = ctx->h_result[0];
+        if ((s = flags_to_status(ctx->h_result[1])) != kRetryDefer) break;
+        // grow the deferred-probe list and run the enqueued call again (same inputs, same output buffer)
+        const arp_atoms again = ctx->last_atoms;
+        const arp_params prm = ctx->last_params;
+        if ((s = grow_defer_list(ctx, again.n)) != ARP_OK) return s;
+        if ((s = arp_contacts_atomic_enqueue(ctx, &again, &prm, ctx->last_out, ctx->last_capacity)) != ARP_OK) return s;
+    }
+    if (s != ARP_OK) return s;
     if (ctx->h_result[0] > ctx->last_capacity) {
         set_error("pair buffer too small: %llu pairs needed, capacity %llu", ctx->h_result[0], (unsigned long long)ctx->last_capacity);
         return ARP_ERR_CAPACITY;
@@ -392,8 +451,16 @@ extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_p
     return ARP_OK;
 }
 
+static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location, arp_pairs *out);
 extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location,
                                           arp_pairs *out) {
+    for (;;) {
+        arp_status s = contacts_atomic_once(ctx, atoms, params, out_location, out);
+        if (s != kRetryDefer) return s;
+        if ((s = grow_defer_list(ctx, atoms->n)) != ARP_OK) return s;  // like the pair buffer: grow, repeat the pass
+    }
+}
+static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location, arp_pairs *out) {
     if (!out) { set_error("null out"); return ARP_ERR_BAD_INPUT; }
     out->n = 0; out->data = nullptr; out->location = out_location;
     arp_status s = check_device(ctx);
@@ -421,7 +488,7 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
                 ctx->out_cap = want;
             }
             launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false);
-            launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof);
+            launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -451,7 +518,7 @@ extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *ato
     arp_pair *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
     if (params->flags & ARP_FLAG_DETERMINISTIC) launch_fill_ordered(d, ctx->ws, dev, total, ctx->stream, prof, only);
-    else launch_emit(d, ctx->ws, dev, total, ctx->stream, prof);
+    else launch_emit(d, ctx->ws, dev, total, ctx->stream, prof, only);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

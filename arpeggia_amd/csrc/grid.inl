@@ -18,18 +18,23 @@ DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, 
         if (!(ext[k] >= 0.0) || !isfinite(ext[k])) ext[k] = 0.0;
         if (!isfinite(lo[k])) lo[k] = 0.0;
     }
-    const uint32_t nm = n_models ? n_models : 1u;
-    // edge slightly above the cutoff so that |dx| <= cutoff can never straddle two cell boundaries after rounding
-    double edge = cutoff * (1.0 + 1e-6);
+    // every model owns at least two z layers (a slab + its separator): model ids the workspace cannot hold (sparse ids such as
+    // 65535 on a ten-atom input) are an input error -- clamped here so that the cell arithmetic stays in range, flagged in `bad`
+    uint32_t nm = n_models ? n_models : 1u;
+    if (2ull * nm > (unsigned long long)ncells_cap) { nm = ncells_cap / 2u; bad |= 2u; }
+    // edge slightly above |cutoff| so that |dx| <= |cutoff| can never straddle two cell boundaries after rounding (the
+    // reference only ever uses cutoff^2, complex.rs:191, so a negative cutoff searches the same sphere)
+    double edge = fabs(cutoff) * (1.0 + 1e-6);
     if (!(edge > 1e-3)) edge = 1e-3;
     double nx, ny, nz;
-    for (;;) {
+    for (int it = 0;; ++it) {
         nx = floor(ext[0] / edge) + 1.0; ny = floor(ext[1] / edge) + 1.0; nz = floor(ext[2] / edge) + 1.0;
         if (nx * ny * (nz + 1.0) * (double)nm <= (double)ncells_cap) break;
+        if (it >= 512) { nx = ny = nz = 1.0; edge = INFINITY; break; }  // unreachable for finite extents (1.26^512 overflows first); a bound, not a hope
         edge *= 1.2599210498948732;  // sparse / huge extents: coarser cells stay correct (edge >= cutoff)
     }
     g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2];
-    g->inv_edge = 1.0 / edge;
+    g->inv_edge = isfinite(edge) ? 1.0 / edge : 0.0;
     g->nx = (uint32_t)nx; g->ny = (uint32_t)ny; g->nz = (uint32_t)nz;
     g->nzt = nm * (g->nz + 1u);
     g->ncells = g->nx * g->ny * g->nzt;
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
             }
             acc.models = use ? max(acc.models, md[u] + 1u) : acc.models;
             acc.bad |= use ? (0x100u << (at[u] & ARP_ATTR_ELEM_MASK)) : 0u;  // bits 8..23: element classes present in the grid
+            acc.bad |= (use & ((at[u] & (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR)) != (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR))) ? (1u << 24) : 0u;  // bit 24: an atom outside L or R
         }
     }
     box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
     __shared__ double s_mn[4][3], s_mx[4][3];
     __shared__ uint32_t s_models[4], s_bad[4];
     for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
-    if (threadIdx.x < 4) result[threadIdx.x] = 0;
+    if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results, [8..31] cycle stamps of diagnostic builds
     BoxAcc acc;
     for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {
         const double *p = partials + 8 * b;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
     // hydrophobic rule -- and the dropped candidates are exactly ones the flag would have filtered out.
     __shared__ double s_bound[4];
     if (prm->flags & ARP_FLAG_CONTACTS_ONLY) {
-        const uint32_t present = acc.bad >> 8, ea = threadIdx.x >> 4, eb = threadIdx.x & 15u;
+        const uint32_t present = (acc.bad >> 8) & 0xFFFFu, ea = threadIdx.x >> 4, eb = threadIdx.x & 15u;
         double b = fmax(prm->s_hphob, fmax(prm->s_ion, prm->s_polar));
         if ((present >> ea) & (present >> eb) & 1u) b = fmax(b, fmax(prm->s_clash[threadIdx.x], fmax(prm->s_cov[threadIdx.x], prm->s_vdw[threadIdx.x])));
         for (int off = 32; off; off >>= 1) b = fmax(b, __shfl_xor(b, off));
@@ -145,7 +151,10 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
             if (b < prm->r2) { prm->r2 = b; cutoff = sqrt(b); }
         }
     }
-    if (threadIdx.x == 0) grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap);
+    if (threadIdx.x == 0) {
+        grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap);
+        g->all_both = (acc.bad >> 24) & 1u ? 0u : 1u;
+    }
 }
 
 DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
@@ -267,7 +276,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
         if (FINISH) {  // the pair-count scan also publishes the result word and the status flags
             result[0] = (unsigned long long)total;
             if (have_out && (unsigned long long)total > capacity) result[1] |= 1ull;
-            if (g->bad) result[1] |= 4ull;
+            if (g->bad & 1u) result[1] |= 4ull;
+            if (g->bad & 2u) result[1] |= 64ull;
         }
     }
 }
@@ -275,20 +285,36 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
 // ---------------------------------------------------------------------------------------------- sort into cells
 constexpr uint32_t kAttrResHasH = 0x80000000u;  // internal: the atom's residue carries hydrogens (set when the atom is placed)
 
+// The pair word of an atom (arp_internal.h Fat::pw).  P = {donor, weak donor, POS, POS, NEG, hydrophobic, CYS SG},
+// Q = {acceptor, acceptor, NEG, POS, NEG, hydrophobic, CYS SG}: (Pa & Qb) | (Pb & Qa) = {donor..acceptor either way
+// (hbond.rs:113-134), weak donor..acceptor (hbond.rs:181-201), POS..NEG (ionic.rs:37-57), POS..POS, NEG..NEG (ionic.rs:59-81),
+// hydrophobic pair (hydrophobic.rs:10-24), CYS SG pair (vdw.rs:46-53)}.
+DEVFN uint32_t make_pair_word(uint32_t attr, bool res_has_h) {
+    const uint32_t don = (attr >> 4) & 1u, acc = (attr >> 5) & 1u, wdon = (attr >> 6) & 1u, pos = (attr >> 7) & 1u, neg = (attr >> 8) & 1u,
+                   hyd = (attr >> 9) & 1u, sg = (attr >> 10) & 1u;
+    const uint32_t P = don | (wdon << 1) | (pos << 2) | (pos << 3) | (neg << 4) | (hyd << 5) | (sg << 6);
+    const uint32_t Q = acc | (acc << 1) | (neg << 2) | (pos << 3) | (neg << 4) | (hyd << 5) | (sg << 6);
+    return (attr & ARP_ATTR_ELEM_MASK) | (P << 8) | (Q << 16) | ((attr & ARP_ATTR_LIGAND) ? kPwLigand : 0u) | ((attr & ARP_ATTR_RECEPTOR) ? kPwReceptor : 0u) |
+           (res_has_h ? kPwResHasH : 0u);
+}
+
 DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so, uint32_t i, uint32_t c, uint32_t d) {
     const double x = in.x[i], y = in.y[i], z = in.z[i];
     const float fx = (float)(x - gp->mx), fy = (float)(y - gp->my), fz = (float)(z - gp->mz);
     so.rec[d] = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
-    Fat f;
-    f.x = x; f.y = y; f.z = z;
-    f.attr = in.attr[i] & ~kAttrResHasH; f.res_ord = in.res_ord[i]; f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i;
-    f.cell = c; f.spare = 0u;
-    // "the residue carries hydrogens" as an attribute bit: the hot kernel never touches the hydrogen tables, the deferred
+    // "the residue carries hydrogens" as a bit of the record: the hot kernel never touches the hydrogen tables, the deferred
     // pass resolves residue -> hydrogens itself (hbond.rs:38-42)
+    bool has_h = false;
     if (in.n_res) {
         const uint32_t r = in.res_id[i];
-        if (in.res_h_ptr[r] < in.res_h_ptr[r + 1]) f.attr |= kAttrResHasH;
+        has_h = in.res_h_ptr[r] < in.res_h_ptr[r + 1];
     }
+    const uint32_t attr = in.attr[i] & ~kAttrResHasH;
+    Fat f;
+    f.x = x; f.y = y; f.z = z;
+    f.pw = make_pair_word(attr, has_h); f.res_ord = in.res_ord[i];
+    f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i; f.cell = c;
+    f.attr = attr | (has_h ? kAttrResHasH : 0u);
     so.fat[d] = f;
 }
 

@@ -80,6 +80,15 @@ bool fit_plane(const std::vector<std::array<double, 3>> &pts, Plane *out);
 // (utils.rs:8-30, python.rs num_threads).  1 = serial (the reference's default), 0 = all hardware threads.
 int host_threads();
 void set_host_threads(int n);
+// Pins the worker count of the calling thread for the lifetime of the scope: n > 0 that many, n == 0 all hardware threads,
+// n < 0 a snapshot of the process-wide default.  parallel_for() is only ever called from the thread that owns the scope.
+struct HostThreadsScope {
+    int prev;
+    explicit HostThreadsScope(int n);
+    ~HostThreadsScope();
+    HostThreadsScope(const HostThreadsScope &) = delete;
+    HostThreadsScope &operator=(const HostThreadsScope &) = delete;
+};
 // fn(begin, end, worker) over [0, n) in contiguous slices, one per worker; serial below `min_per_worker` items per worker.
 template <class F>
 void parallel_for(size_t n, size_t min_per_worker, F &&fn) {

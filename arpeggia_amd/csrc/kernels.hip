@@ -33,24 +33,34 @@ DEVFN double sq_dist(double ax, double ay, double az, double bx, double by, doub
     double dx = __dsub_rn(bx, ax), dy = __dsub_rn(by, ay), dz = __dsub_rn(bz, az);
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
-DEVFN uint32_t wave_min_u32(uint32_t v) {
-    for (int off = 32; off; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off));
-    return v;
+// Wave-wide min / max on the vector ALU's data-parallel primitives (DPP): a 16-lane inclusive scan by row shifts, then the
+// row results hop to the later rows (row_bcast 15 / 31) and lane 63 holds the answer.  __shfl_xor compiles to six ds_bpermute
+// round trips through the LDS crossbar, each waited for: ~1 us per reduction in a wave that has little else to overlap.
+template <bool MAX>
+DEVFN uint32_t wave_reduce_u32(uint32_t v) {
+    const uint32_t id = MAX ? 0u : 0xFFFFFFFFu;
+    auto op = [](uint32_t a, uint32_t b) { return MAX ? max(a, b) : min(a, b); };
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-DEVFN uint32_t wave_max_u32(uint32_t v) {
-    for (int off = 32; off; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
-    return v;
-}
+DEVFN uint32_t wave_min_u32(uint32_t v) { return wave_reduce_u32<false>(v); }
+DEVFN uint32_t wave_max_u32(uint32_t v) { return wave_reduce_u32<true>(v); }
 DEVFN void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // ---------------------------------------------------------------------------------------------- grid build, scan, sort
 #include "grid.inl"
 
 // ---------------------------------------------------------------------------------------------- per-pair rules
-struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB)
+struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB) + the pair-rule table (2 KB)
     double s_clash[256], s_cov[256], s_vdw[256], s_hacc[16];
     double r2, s_ion, s_polar, s_hphob;
-    uint32_t contacts_only;
+    uint32_t contacts_only, all_both;
+    uint32_t lut[512];    // pair_lut_entry(): rows decided by class bits and distance level alone
 };
 
 // should_compare_entities(x, y, symmetric = true) for x in L, y in R (complex.rs:76-131, 200-206), evaluated for both
@@ -60,7 +70,7 @@ struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB)
 DEVFN int orient(const Fat &a, const Fat &b) {
     const bool same_model = (a.crm >> 16) == (b.crm >> 16);             // :96-98
     const uint32_t ca = a.crm & 0xFFFFu, cb = b.crm & 0xFFFFu;
-    const bool aL = a.attr & ARP_ATTR_LIGAND, aR = a.attr & ARP_ATTR_RECEPTOR, bL = b.attr & ARP_ATTR_LIGAND, bR = b.attr & ARP_ATTR_RECEPTOR;
+    const bool aL = a.pw & kPwLigand, aR = a.pw & kPwReceptor, bL = b.pw & kPwLigand, bR = b.pw & kPwReceptor;
     // same chain (:108,:113): (e2 > 1) && (e1 < e2 - 1)  <=>  e1 + 1 < e2   (ordinals are far below 2^32 - 1)
     const bool ab_chain = a.res_ord + 1u < b.res_ord, ba_chain = b.res_ord + 1u < a.res_ord;
     const bool both = aL & aR & bL & bR;                                 // :124-129
@@ -69,6 +79,16 @@ DEVFN int orient(const Fat &a, const Fat &b) {
     const bool ab = same_chain ? ab_chain : ab_cross, ba = same_chain ? ba_chain : ba_cross;
     const bool o1 = same_model & aL & bR & ab, o2 = same_model & bL & aR & ba;
     return o1 ? 1 : (o2 ? 2 : 0);
+}
+// The same when every atom is in both sets (groups "/", GridParams::all_both): the L/R tests drop out, a same-chain pair is a
+// candidate iff the ordinals differ by >= 2 (:113), a cross-chain pair of one model always (:124-129), and in both cases the
+// ligand is the atom with the smaller (chain rank, ordinal) key.
+DEVFN int orient_all_both(const Fat &a, const Fat &b) {
+    const bool same_model = ((a.crm ^ b.crm) >> 16) == 0u, same_mc = a.crm == b.crm;
+    const bool gap = (b.res_ord - a.res_ord + 1u) > 2u;                  // |ordinal difference| >= 2
+    const bool valid = same_model & (!same_mc | gap);
+    const unsigned long long ka = ((unsigned long long)a.crm << 32) | a.res_ord, kb = ((unsigned long long)b.crm << 32) | b.res_ord;
+    return valid ? (kb < ka ? 2 : 1) : 0;
 }
 
 DEVFN double angle_deg(const double a[3], const double b[3], const double c[3]) {
@@ -182,49 +202,53 @@ DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, double s, cons
     return clash ? (1u << ARP_StericClash) : kind;                                              // complex.rs:233-235
 }
 
-// The same rules for the hot kernel (no probes): pair predicates as bits of a few integer words instead of one boolean per
-// rule -- the boolean form compiled to ~100 vector instructions per batch (0/1 materialisations and selects), this one to
-// about half.  A pair is handed to the deferred pass (which runs classify<true>, exact for every pair) when a probe MAY be
-// needed: a donor/acceptor pair within 4.0 A where either residue carries hydrogens (a superset of hbond.rs:37-42,81-86:
-// the reference only looks at the donor's residue), or a CYS SG..SG pair in the covalent band (vdw.rs:46-53).
-// Attribute bits: DONOR 4, ACCEPTOR 5, WEAK_DONOR 6, POS 7, NEG 8, HYDROPHOBIC 9, CYS_SG 10, residue-has-H 31.
-DEVFN uint32_t classify_fast(const LdsParams &prm, double s, uint32_t A, uint32_t B, uint32_t have_res) {
-    const uint32_t e = ((A & ARP_ATTR_ELEM_MASK) << 4) | (B & ARP_ATTR_ELEM_MASK);
-    const bool clash = s < prm.s_clash[e], cov = s < prm.s_cov[e], vdw = s < prm.s_vdw[e];  // vdw.rs:32-43 (strict <)
-    const uint32_t near4 = s < prm.s_ion ? 1u : 0u, near35 = s < prm.s_polar ? 1u : 0u, near45 = s < prm.s_hphob ? 1u : 0u;
-    const uint32_t A1 = A >> 1, B1 = B >> 1;
-    const uint32_t x = (A & B1) | (B & A1);      // bit 4: donor..acceptor either way (hbond.rs:113-134), bit 7: POS..NEG either way
-    const uint32_t y = (A1 & B) | (B1 & A);      // bit 5: weak donor (6 -> 5)..acceptor either way (hbond.rs:181-201)
-    const uint32_t both = A & B;                 // bit 7 / 8: POS..POS / NEG..NEG, bit 9: hydrophobic pair, bit 10: CYS SG pair
-    const uint32_t strong = (x >> 4) & 1u, weak = (y >> 5) & 1u, ion = (x >> 7) & 1u;
-    const uint32_t rep = ((both | (both >> 1)) >> 7) & 1u, hy = (both >> 9) & 1u, sg = (both >> 10) & 1u;
-    const uint32_t any_h = (A | B) >> 31;
-    const uint32_t probe = (near4 & (strong | weak) & any_h) | ((cov ? 1u : 0u) & sg & have_res);
+// The same rules for the hot kernels (no probes), table-driven.  Everything that does not depend on the element pair is a
+// function of the seven pair predicates W = (Pa & Qb) | (Pb & Qa) (Fat::pw) and the distance level L = number of the nested
+// bounds {4.5, 4.0, 3.5} the pair is inside: one 512-entry LDS table read replaces ~30 vector instructions of bit logic.
+// Entry = the rows IonicBond / PolarContact / WeakPolarContact / IonicRepulsion / HydrophobicContact (complex.rs:238-296 without a
+// probe), bit 30 = "a donor..acceptor pair within 4.0 A" (hbond.rs:37,81: a hydrogen probe decides if a residue carries hydrogens),
+// bit 29 = CYS SG pair (vdw.rs:46-53: the dihedral probe decides inside the covalent band).
+DEVFN uint32_t pair_lut_entry(uint32_t idx) {
+    const uint32_t W = idx & 0x7Fu, L = idx >> 7;
+    const uint32_t strong = W & 1u, weak = (W >> 1) & 1u, ion = (W >> 2) & 1u, rep = ((W >> 3) | (W >> 4)) & 1u, hy = (W >> 5) & 1u, sg = (W >> 6) & 1u;
+    const uint32_t near45 = L >= 1u, near4 = L >= 2u, near35 = L >= 3u;
     const uint32_t ionic = near4 & ion;                                                          // ionic.rs:11-22,37-57
-    uint32_t kind = cov ? (1u << ARP_CovalentBond) : (vdw ? (1u << ARP_VanDerWaalsContact) : 0u);
-    kind |= ionic << ARP_IonicBond;
-    kind |= (strong & near35 & ~ionic) << ARP_PolarContact;                                      // complex.rs:240-251 without a probe
-    kind |= (weak & near35) << ARP_WeakPolarContact;
-    kind |= (near4 & rep) << ARP_IonicRepulsion;                                                 // ionic.rs:25-35,59-81
-    kind |= (near45 & hy) << ARP_HydrophobicContact;                                             // hydrophobic.rs:10-24
-    kind = probe ? kDeferKind : kind;
+    uint32_t k = ionic << ARP_IonicBond;
+    k |= (strong & near35 & (ionic ^ 1u)) << ARP_PolarContact;                                   // complex.rs:240-251 without a probe
+    k |= (weak & near35) << ARP_WeakPolarContact;
+    k |= (near4 & rep) << ARP_IonicRepulsion;                                                    // ionic.rs:25-35,59-81
+    k |= (near45 & hy) << ARP_HydrophobicContact;                                                // hydrophobic.rs:10-24
+    k |= (near4 & (strong | weak)) << 30;
+    k |= sg << 29;
+    return k;
+}
+// A pair is handed to the deferred pass (which runs classify<true>, exact for every pair) when a probe MAY be needed: a
+// donor/acceptor pair within 4.0 A where either residue carries hydrogens (a superset of hbond.rs:37-42,81-86: the reference
+// only looks at the donor's residue), or a CYS SG..SG pair in the covalent band (vdw.rs:46-53).
+DEVFN uint32_t classify_fast(const LdsParams &prm, double s, uint32_t pa, uint32_t pb, uint32_t have_res) {
+    const uint32_t e = ((pa & ARP_ATTR_ELEM_MASK) << 4) | (pb & ARP_ATTR_ELEM_MASK);
+    const bool clash = s < prm.s_clash[e], cov = s < prm.s_cov[e], vdw = s < prm.s_vdw[e];  // vdw.rs:32-43 (strict <)
+    const uint32_t L = (s < prm.s_hphob ? 1u : 0u) + (s < prm.s_ion ? 1u : 0u) + (s < prm.s_polar ? 1u : 0u);  // d <= 4.5 / 4.0 / 3.5
+    const uint32_t W = (((pa >> 8) & (pb >> 16)) | ((pb >> 8) & (pa >> 16))) & 0x7Fu;
+    const uint32_t t = prm.lut[W | (L << 7)];
+    const uint32_t probe = ((t >> 30) & ((pa | pb) >> 31)) | ((cov ? 1u : 0u) & (t >> 29) & have_res);
+    uint32_t kind = (t & 0x1FFFFFFFu) | (cov ? (1u << ARP_CovalentBond) : (vdw ? (1u << ARP_VanDerWaalsContact) : 0u));
+    kind = (probe & 1u) ? kDeferKind : kind;
     return clash ? (1u << ARP_StericClash) : kind;                                               // complex.rs:233-235
 }
 
 // (float) of the correctly rounded f64 square root -- what the reference stores in the table (mod.rs:148) -- without the
-// library sqrt on the common path.  f32 rsq seed r (relative error e0 <= 2^-22.4), one coupled Newton step in f64
-// (y1 = sqrt(s)(1 - e0^2), h1 = (1 - e0^2) / (2 sqrt(s))) and the residual correction y2 = y1 + (s - y1^2) h1, whose error
-// is O(e0^4) plus the rounding of the last FMA: < 2 ulp(f64).  That cannot change the f32 rounding unless y2 sits within a
-// few f64 ulps of an f32 rounding boundary (probability ~1e-8 per pair); only then, and for degenerate s, the exact library
-// routine runs -- behind a WAVE-UNIFORM branch: left to the compiler, both paths were evaluated for every pair.
+// library sqrt on the common path.  f32 rsq seed r = (1 + e) / sqrt(s), |e| < 2^-21.5; y0 = s r; one residual correction
+// y = y0 + (s - y0^2) (r / 2) = sqrt(s) (1 - 1.5 e^2 - ...): relative error < 1.7e-13, i.e. < 1600 ulp(f64).  That cannot change
+// the f32 rounding unless y sits within 2048 f64 ulps of an f32 rounding boundary (probability 4e-6 per pair); only then, and
+// for degenerate s, the exact library routine runs -- behind a WAVE-UNIFORM branch: left to the compiler, both paths were
+// evaluated for every pair.
 DEVFN float dist_f32(double s) {
     const double r = (double)__frsqrt_rn((float)s);
-    double y = s * r, h = 0.5 * r;
-    const double e = __fma_rn(-h, y, 0.5);
-    y = __fma_rn(y, e, y); h = __fma_rn(h, e, h);
-    y = __fma_rn(__fma_rn(-y, y, s), h, y);
+    const double y0 = s * r, hr = 0.5 * r;
+    const double y = __fma_rn(__fma_rn(-y0, y0, s), hr, y0);
     const uint32_t low = (uint32_t)__double_as_longlong(y) & 0x1FFFFFFFu;  // the 29 bits a cast to f32 drops
-    const bool exact = !(s > 1e-30 && s < 1e30) | (low - (0x10000000u - 16u) <= 32u);  // degenerate, or near the midpoint
+    const bool exact = !(s > 1e-30 && s < 1e30) | (low - (0x10000000u - 2048u) <= 4096u);  // degenerate, or near the midpoint
     float out = (float)y;
     if (__ballot(exact) != 0ull) {
         asm volatile("" ::: "memory");  // keep this a branch (no speculation of the long sequence)
@@ -235,5 +259,6 @@ DEVFN float dist_f32(double s) {
 
 // ---------------------------------------------------------------------------------------------- pair search + launch
 #include "pairs.inl"
+#include "pairs_lds.inl"
 
 }  // namespace arp

@@ -24,12 +24,18 @@ enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2, kCountContacts = 3
 
 constexpr int kWavesPerBlock = 8;
 constexpr int kQueue = 128;
-constexpr uint32_t kChunk = 256;            // neighbour records per staged chunk (4 KB)
+#ifndef ARP_CHUNK
+#define ARP_CHUNK 256
+#endif
+constexpr uint32_t kChunk = ARP_CHUNK;      // neighbour records per staged chunk (4 KB)
 constexpr uint32_t kBlock = 16;             // prefilter tests per lane between two compaction steps
 constexpr uint32_t kReadAhead = 4;         // LDS reads in flight per lane in the prefilter (more costs a wave of occupancy in registers)
 constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
-constexpr uint32_t kEmitBlocks = 768;       // emit mode: 3 blocks of 8 waves per CU (6 waves per SIMD)
-constexpr int kEmitWavesPerSimd = 6;         // register budget of the emit kernel: 80 VGPRs
+#ifndef ARP_EMIT_WPS
+#define ARP_EMIT_WPS 6
+#endif
+constexpr int kEmitWavesPerSimd = ARP_EMIT_WPS;   // register budget of the emit kernel: 80 VGPRs at 6, 64 at 8
+constexpr uint32_t kEmitBlocks = 128u * ARP_EMIT_WPS;  // emit mode: blocks of 8 waves, ARP_EMIT_WPS waves per SIMD
 constexpr uint32_t kGrab = 1;              // wave-tasks drawn per atomic
 #ifndef ARP_CHUNK_RECORDS
 #define ARP_CHUNK_RECORDS 2048
@@ -126,22 +132,49 @@ DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head,
     }
 }
 
+constexpr uint32_t kWaveAllBoth = 1u, kWaveContactsOnly = 2u;  // wave-uniform switches of process_batch, kept in a scalar register
+// Record p of the cell-sorted array through a 32-bit byte offset from the (scalar) base: 48 p = (p + 2 p) << 4 is two full-rate
+// instructions and the load takes the scalar-base form, where a 64-bit multiply-add is a quarter-rate one.  Valid below 2^32 / 48
+// slots; the launchers route larger inputs (kBigSlots) to the variants with inline probes, which address in 64 bits.
+constexpr uint32_t kBigSlots = 0x5000000u;
+template <bool BIG = false>
+DEVFN const Fat &fat_at(const Fat *base, uint32_t p) {
+    if (BIG) return base[p];
+    uint32_t off;  // (as inline asm: the optimiser folds the shifts back into one quarter-rate v_mul_lo_u32)
+    asm("v_lshl_add_u32 %0, %1, 1, %1\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(off) : "v"(p));
+    return *reinterpret_cast<const Fat *>(reinterpret_cast<const char *>(base) + (size_t)off);
+}
+// decision bounds and the pair-rule table -> LDS, once per block (ends with a barrier)
+DEVFN void load_lds_params(LdsParams &prm, const DevParams *dprm, const GridParams *gp) {
+    const double *src = dprm->s_clash;
+    double *dst = prm.s_clash;
+    for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < 512u; k += blockDim.x) prm.lut[k] = pair_lut_entry(k);
+    if (threadIdx.x == 0) {
+        prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
+        prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
+        prm.all_both = gp ? gp->all_both : 0u;
+    }
+    __syncthreads();
+}
+
 // Phase 2 on up to 64 survivors.  Returns the number of valid candidate pairs of the batch.  PROBES == false keeps the
 // rare data-dependent rules (hydrogen-bond angle test over the donor residue's hydrogens, disulfide dihedral) out of the
 // hot kernel -- they cost it half its occupancy in registers: such pairs go to a list that k_pairs_deferred finishes.
 template <int MODE, bool PROBES>
 DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
-                             unsigned long long base, uint32_t emitted, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
+                             unsigned long long base, uint32_t emitted, const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags) {
 #if defined(ARP_ABLATE) && (ARP_ABLATE == 1 || ARP_ABLATE == 9)   // timing ablations: no exact phase at all (results are wrong by construction)
     return (uint32_t)__popcll(__ballot(active));
 #endif
     bool valid = false, swap = false;
     double s = 0.0;
     Fat a, b;
+    const bool all_both = !PROBES && (wflags & kWaveAllBoth);  // wave-uniform (held in a scalar register): a scalar branch, no divergence
     if (active) {
-        a = so.fat[ent.x]; b = so.fat[ent.y];
+        a = fat_at<PROBES>(so.fat, ent.x); b = fat_at<PROBES>(so.fat, ent.y);  // the probe variants keep 64-bit addressing (inputs of any size)
         s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
-        const int o = orient(a, b);
+        const int o = all_both ? orient_all_both(a, b) : orient(a, b);
         valid = (s <= prm.r2) & (o != 0);  // rstar: inclusive
         swap = o == 2;
     }
@@ -154,10 +187,10 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (valid) {
 #if defined(ARP_ABLATE) && ARP_ABLATE == 13   // timing ablation: no classification
-            r.w = (a.attr ^ b.attr) & 1u;
+            r.w = (a.pw ^ b.pw) & 1u;
 #else
             if (PROBES) r.w = classify<true>(in, prm, s, a, b, swap, result);
-            else r.w = classify_fast(prm, s, a.attr, b.attr, in.n_res != 0u ? 1u : 0u);
+            else r.w = classify_fast(prm, s, a.pw, b.pw, in.n_res != 0u ? 1u : 0u);
 #endif
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
 #if defined(ARP_ABLATE) && ARP_ABLATE == 14   // timing ablation: no output distance
@@ -166,7 +199,7 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
             r.z = __float_as_uint(dist_f32(s));
 #endif
         }
-        if (prm.contacts_only) {  // ARP_FLAG_CONTACTS_ONLY: candidates without any interaction are dropped (kDeferKind != 0 stays)
+        if (wflags & kWaveContactsOnly) {  // ARP_FLAG_CONTACTS_ONLY: candidates without any interaction are dropped (kDeferKind != 0 stays)
             valid = valid && r.w != 0u;
             vm = __ballot(valid);
         }
@@ -267,20 +300,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
     __shared__ LdsParams prm;
     __shared__ WaveLds<MODE> wl[kWavesPerBlock];
     __shared__ BlockLds bl;
-    {   // decision bounds -> LDS once per block
-        const double *src = dprm->s_clash;
-        double *dst = prm.s_clash;
-        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
-        if (threadIdx.x == 0) {
-            prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
-            prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
-            bl.alloc_state = kAllocEmpty | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
-            bl.defer_state = kAllocEmpty | kDeferChunk;
-        }
-        __syncthreads();
+    load_lds_params(prm, dprm, gp);
+    if (threadIdx.x == 0) {
+        bl.alloc_state = kAllocEmpty | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
+        bl.defer_state = kAllocEmpty | kDeferChunk;
     }
+    __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
+    const uint32_t wflags = (gp->all_both ? kWaveAllBoth : 0u) | ((dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u);
     const double r2m = gp->r2m;
     WaveLds<MODE> &w = wl[wave];
     // Task distribution: blocks b and b+8 share an XCD (and its private L2), so block group (b mod 8) owns one contiguous
@@ -392,7 +420,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
                             wave_lds_fence();  // lanes read entries other lanes wrote
                             const uint2 ent = w.queue[q1 + lane];
                             wave_lds_fence();
-                            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, true, base, emitted, tg, result, lane);
+                            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, true, base, emitted, tg, result, lane, wflags);
                         }
                         qlen = q1;
                     }
@@ -405,7 +433,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
             wave_lds_fence();
             const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
             wave_lds_fence();
-            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, base, emitted, tg, result, lane);
+            emitted += process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, base, emitted, tg, result, lane, wflags);
             qlen = 0;
         }
         if ((MODE == kCountTasks || MODE == kCountContacts) && lane == 0) task_count[t] = emitted;
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
             wave_lds_fence();
             const uint2 ent = act ? w.queue[lane] : make_uint2(0u, 0u);
             wave_lds_fence();
-            process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, 0ull, 0u, tg, result, lane);
+            process_batch<MODE, PROBES>(in, prm, so, w, bl, ent, act, 0ull, 0u, tg, result, lane, wflags);
         }
         emit_epilogue(bl, hole_list + blockIdx.x, tg);
     }
@@ -435,25 +463,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
     __shared__ LdsParams prm;
     __shared__ WaveLds<kEmit> wl[kWavesPerBlock];
     __shared__ BlockLds bl;
-    {
-        const double *src = dprm->s_clash;
-        double *dst = prm.s_clash;
-        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
-        if (threadIdx.x == 0) {
-            prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
-            prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
-            bl.alloc_state = kAllocEmpty | kChunkRecords;
-            bl.defer_state = kAllocEmpty | kDeferChunk;
-        }
-        __syncthreads();
+    load_lds_params(prm, dprm, nullptr);
+    if (threadIdx.x == 0) {
+        bl.alloc_state = kAllocEmpty | kChunkRecords;
+        bl.defer_state = kAllocEmpty | kDeferChunk;
     }
+    __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wflags = (dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u;
     const unsigned long long n = min(result[3] * kDeferChunk, tg.defer_cap);  // result[3] counts list chunks
     for (unsigned long long e0 = ((unsigned long long)blockIdx.x * kWavesPerBlock + wave) * 64ull; e0 < n; e0 += (unsigned long long)gridDim.x * kWavesPerBlock * 64ull) {
         uint2 ent = make_uint2(0xFFFFFFFFu, 0u);
         if (e0 + lane < n) ent = tg.defer_list[e0 + lane];
         const bool act = ent.x != 0xFFFFFFFFu;  // chunk tails hold sentinels
-        process_batch<kEmit, true>(in, prm, so, wl[wave], bl, ent, act, 0ull, 0u, tg, result, lane);
+        process_batch<kEmit, true>(in, prm, so, wl[wave], bl, ent, act, 0ull, 0u, tg, result, lane, wflags);
     }
     emit_epilogue(bl, hole_list + blockIdx.x, tg);
 }
@@ -462,16 +485,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_patch_deferred(DevAtoms in, const DevParams *dprm, Sorted so, EmitTarget tg,
                                                                          unsigned long long *result) {
     __shared__ LdsParams prm;
-    {
-        const double *src = dprm->s_clash;
-        double *dst = prm.s_clash;
-        for (uint32_t k = threadIdx.x; k < 3 * 256 + 16; k += blockDim.x) dst[k] = src[k];
-        if (threadIdx.x == 0) {
-            prm.r2 = dprm->r2; prm.s_ion = dprm->s_ion; prm.s_polar = dprm->s_polar; prm.s_hphob = dprm->s_hphob;
-            prm.contacts_only = dprm->flags & ARP_FLAG_CONTACTS_ONLY;
-        }
-        __syncthreads();
-    }
+    load_lds_params(prm, dprm, nullptr);
     const unsigned long long n = min(result[3] * kDeferChunk, tg.defer_cap) / 2ull;  // {entry, position} pairs
     const uint4 *list = reinterpret_cast<const uint4 *>(tg.defer_list);
     for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (unsigned long long)gridDim.x * blockDim.x) {
@@ -549,7 +563,8 @@ __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_li
         result[0] = P;
         if (P > tg.capacity) result[1] |= 1ull;
         if (F != T) result[1] |= 16ull;  // internal consistency check of the plan
-        if (g->bad) result[1] |= 4ull;
+        if (g->bad & 1u) result[1] |= 4ull;
+        if (g->bad & 2u) result[1] |= 64ull;
     }
     if (P > tg.capacity || F != T) return;  // the caller's buffer cannot hold the table: report the size only
     for (unsigned long long m = (unsigned long long)blockIdx.x * kFixThreads + i; m < F; m += (unsigned long long)gridDim.x * kFixThreads) {
@@ -644,7 +659,7 @@ void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profi
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof,
                          bool contacts_only) {
     if (prof) prof->begin("pairs_fill", st);
-    if (contacts_only) {
+    if (contacts_only || in.n >= kBigSlots) {
         // the filter needs every kind before a record is placed: probes inline (2 waves per SIMD)
         EmitTarget tg{out, capacity, nullptr, 0ull, nullptr, 0ull};
         hipLaunchKernelGGL((k_pairs<kFillOrdered, true>), dim3(blocks_for(in.n, kPairBlocks)), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid,
@@ -663,8 +678,19 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
     if (prof) prof->end(st);
 }
 
+void launch_emit_x(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
-void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
+void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only) {
+    if (in.n >= kBigSlots) {  // beyond the 32-bit record offsets of the single-pass kernel: count + ordered fill with inline probes
+        launch_count(in, ws, st, prof, capacity, true, contacts_only);
+        launch_fill_ordered(in, ws, out, capacity, st, prof, contacts_only);
+        return;
+    }
+    // ARP_EMIT_KERNEL=lds selects k_pairs_x (pairs_lds.inl): both operands of the exact phase out of LDS.  Measured on S2 10^6 atoms
+    // (profiles/r02_emit_kernels.txt) it moves 6x less L2 traffic but runs at 3 waves per SIMD and is issue-bound there (295 us
+    // against 240 us for this kernel), so the gather kernel stays the default.
+    static const bool use_lds_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'l'; }();
+    if (use_lds_kernel) { launch_emit_x(in, ws, out, capacity, st, prof); return; }
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1600)
         const char *e = getenv("ARP_EMIT_BLOCKS");

@@ -2,6 +2,7 @@
 // per-atom preparation the reference redoes with string matching for every pair (hbond.rs, ionic.rs, hydrophobic.rs):
 // here every atom is classified ONCE into an attribute word and the hierarchy is flattened into SoA columns the GPU reads.
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cctype>
 #include <chrono>
@@ -507,12 +508,20 @@ using namespace arp;
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------
 namespace arp {
-static int g_host_threads = 1;
-int host_threads() { return g_host_threads; }
-void set_host_threads(int n) {
+// The process-wide default (arp_set_num_threads) is atomic; every table call works on its OWN snapshot (HostThreadsScope), so a
+// concurrent arp_set_num_threads / contacts(num_threads=k) on another thread cannot change the slicing between two passes of a call.
+static std::atomic<int> g_host_threads{1};
+static thread_local int tl_host_threads = 0;  // > 0 inside a HostThreadsScope
+static int clamp_threads(int n) {
     if (n <= 0) n = (int)std::thread::hardware_concurrency();
-    g_host_threads = std::max(1, std::min(n, 64));
+    return std::max(1, std::min(n, 64));
 }
+int host_threads() { return tl_host_threads > 0 ? tl_host_threads : g_host_threads.load(std::memory_order_relaxed); }
+void set_host_threads(int n) { g_host_threads.store(clamp_threads(n), std::memory_order_relaxed); }
+HostThreadsScope::HostThreadsScope(int n) : prev(tl_host_threads) {
+    tl_host_threads = n < 0 ? g_host_threads.load(std::memory_order_relaxed) : clamp_threads(n);
+}
+HostThreadsScope::~HostThreadsScope() { tl_host_threads = prev; }
 }  // namespace arp
 extern "C" void arp_set_num_threads(int32_t n) { arp::set_host_threads(n); }
 extern "C" int32_t arp_get_num_threads(void) { return arp::host_threads(); }

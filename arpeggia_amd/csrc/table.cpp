@@ -245,8 +245,14 @@ struct Row {
 
 extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp, double dist_cutoff,
                                        arp_table **out) {
+    return arp_get_contacts_mt(ctx, s, groups, vdw_comp, dist_cutoff, -1, out);
+}
+
+extern "C" arp_status arp_get_contacts_mt(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp, double dist_cutoff,
+                                          int32_t num_threads, arp_table **out) {
     if (!s || !out || !groups) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     *out = nullptr;
+    HostThreadsScope threads(num_threads);  // one worker count for every pass of this call
     // ARP_TIMING=1: per-stage wall times on stderr (diagnostic)
     const bool timing = getenv("ARP_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -360,7 +366,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
     // Ring centroids in a hash grid (cell edge = the larger of the two search radii): the reference walks an R*-tree for the
     // ring-atom rows and ALL ring pairs for the ring-ring rows (complex.rs:354-405, O(R^2)); both become linear here.
     const double r2 = dist_cutoff * dist_cutoff;
-    const double cell_edge = std::max(std::max(dist_cutoff, 6.0), 1e-3);
+    const double cell_edge = std::max(std::max(std::fabs(dist_cutoff), 6.0), 1e-3);  // the reference only uses cutoff^2 (complex.rs:303)
     auto cell_of = [&](const double q[3], int64_t c[3]) { for (int k = 0; k < 3; k++) c[k] = (int64_t)std::floor(q[k] / cell_edge); };
     auto cell_key = [](int32_t model, const int64_t c[3]) {
         uint64_t h = (uint64_t)(uint32_t)model * 0x9E3779B97F4A7C15ull;

@@ -202,6 +202,11 @@ int32_t arp_get_num_threads(void);
 /* ---- the table: replaces arpeggia::get_contacts (mod.rs:61-137) ---- */
 arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp,
                             double dist_cutoff, arp_table **out);
+/* The same with the host worker count of THIS call given explicitly (the reference sizes a scoped rayon pool per call,
+ * utils.rs:8-30): num_threads > 0 that many, 0 all hardware threads, < 0 the process-wide default of arp_set_num_threads.
+ * Concurrent calls with different counts do not interfere. */
+arp_status arp_get_contacts_mt(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp,
+                               double dist_cutoff, int32_t num_threads, arp_table **out);
 void arp_table_free(arp_table *t);
 uint64_t arp_table_rows(const arp_table *t);
 /* Column by reference name (mod.rs:140-181,209-211): "model" u32; "interaction" i32 code; "distance" f32;

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B bench runs in one gpurun call.  Usage: bash tests/run_gpu_ab.sh TAG "ENV1=.. ENV2=.." "ENV.." ...   (each arg = one env set)
+# BENCH_ARGS adds bench flags; ablation builds need BENCH_ARGS=--no-check
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
