@@ -38,6 +38,8 @@ struct GridParams {
     uint32_t all_both;    // every heavy atom is in the ligand AND the receptor set (groups "/"): orient() takes its short form
     double mx, my, mz;    // box midpoint: the f32 prefilter records are relative to it (halves their magnitude)
     double r2m;           // prefilter threshold on d^2 in f64: r2 + storage margin + dot-form margin
+    const double *model_org;  // packed batches: per model {origin xyz, midpoint xyz} -- every member sits in a grid slab of its own
+                              // position, however far apart the members are in space; nullptr = one origin for all models
 };
 
 // Device view of the caller's SoA (all device pointers).
@@ -48,6 +50,7 @@ struct DevAtoms {
     const uint16_t *chain_rank, *model;
     const uint32_t *res_id, *res_h_ptr, *res_h_idx, *res_cb, *res_sg;
     uint32_t n_res;
+    uint32_t per_model;   // packed batch: size the grid by the largest member and give every model its own origin
 };
 
 // Exact-phase record of one heavy atom, 48 B = three 16-byte parts.  The hot kernels read parts 0 and 1 whole and the first
@@ -98,6 +101,22 @@ struct Workspace {
     unsigned long long defer_cap;
     uint32_t ncells_cap;
     uint32_t n_cap;
+    uint32_t *model_box;      // per-model bounding boxes of a packed batch: 65536 x {min xyz, max xyz} as order-preserving f32 codes
+    double *model_org;        // 65536 x {origin xyz, midpoint xyz}
+};
+
+// Device view of one pack (batch.inl): the members' arrays back to back + the descriptor table {first atom, first residue, first
+// hydrogen-list entry, model offset} x (K + 1) and the per-member scratch of the renumbering and of the pair-list split.
+struct PackDesc {             // entry m of K + 1 (the last one is the sentinel holding the totals)
+    uint32_t first_atom, first_res, first_h, model_off;
+};
+struct PackArrays {
+    uint32_t n, n_res, n_h, K;
+    PackDesc *desc;
+    uint16_t *model;
+    uint32_t *res_id, *res_h_ptr, *res_cb, *res_sg, *res_h_idx;
+    uint32_t *n_models, *status;             // K, 1
+    unsigned long long *count, *offset, *cursor;  // K, K + 1, K
 };
 
 struct Profiler {
@@ -118,5 +137,7 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
                          bool contacts_only);
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only);
 unsigned long long emit_scratch_records();
+void launch_pack_fix(const PackArrays &pa, hipStream_t st);
+void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, bool ordered, hipStream_t st);
 
 }  // namespace arp

@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <numeric>
+#include <string>
 #include <sys/mman.h>
 #include <system_error>
 #include <thread>
@@ -99,6 +101,11 @@ struct arp_context {
     char *bounce[2] = {nullptr, nullptr};   // pinned staging of large device -> host copies
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     uint64_t out_cap = 0;
+    arp_pair *grp_buf = nullptr;            // batch path: the pack's pair list grouped by member (device) ...
+    uint64_t grp_cap = 0;
+    char *out_pinned = nullptr;             // ... and its pinned landing block on the host
+    unsigned long long *h_offsets = nullptr;  // pinned: per-member offsets into the grouped list (+ the pack status word)
+    uint64_t h_offsets_cap = 0;
     DevParams *h_params = nullptr;         // pinned
     unsigned long long *h_result = nullptr;  // pinned [2]
     arp_params last_params{};
@@ -149,6 +156,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 32);  // result[8..31]: cycle stamps of diagnostic builds (ARP_STAMP)  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
+    A(w.model_box, 65536u * 6u); A(w.model_org, 65536u * 6u);
     w.defer_cap = (uint64_t)ctx->defer_scale * std::max<uint64_t>(16 * cap, 1u << 20) + (1u << 20);  // + one partly used 512-entry chunk per block
     if (const char *dbg = getenv("ARP_DEBUG_DEFER_ENTRIES")) {  // tests: a tiny list, so that the grow-and-repeat path runs
         const long v = atol(dbg);
@@ -163,7 +171,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
         // added to Workspace without its allocation now fails this check on the host instead of faulting on the device.)
         const void *members[] = {w.partials, w.tickets, w.grid, w.params, w.cell_of_atom, w.rank_of_atom, w.cell_count, w.cell_start, w.perm, w.slot_cell,
                                  w.sorted.rec, w.sorted.fat, w.task_count, w.task_base, w.scan_tmp, w.scan_tmp64, w.result, w.hole_list, w.scratch,
-                                 w.task_ctr, w.defer_list};
+                                 w.task_ctr, w.defer_list, w.model_box, w.model_org};
         for (const void *m : members)
             if (!m) { free_workspace(ctx); set_error("internal error: a workspace member was not allocated"); return ARP_ERR_HIP; }
     }
@@ -209,6 +217,9 @@ extern "C" void arp_context_destroy(arp_context *ctx) {
     free_workspace(ctx);
     free_staged(ctx);
     if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+    if (ctx->grp_buf) (void)hipFree(ctx->grp_buf);
+    if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
+    if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
     for (int k = 0; k < 2; k++) { if (ctx->bounce[k]) (void)hipHostFree(ctx->bounce[k]); if (ctx->bounce_ev[k]) (void)hipEventDestroy(ctx->bounce_ev[k]); }
     if (ctx->h_params) (void)hipHostFree(ctx->h_params);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
@@ -545,127 +556,249 @@ extern "C" void arp_pairs_free(arp_pairs *pairs) {
 }
 
 // ---- batches of independent structures ---------------------------------------------------------------------------
-// Small structures do not fill the chip (a 5k-atom structure is ~80 wave tasks for 256 CUs and the per-launch fixed
-// costs dominate), so a device's share of the batch is PACKED: consecutive structures are concatenated into one SoA
-// with their models renumbered to be distinct.  The reference never pairs atoms of different models
-// (complex.rs:96-98, 201-207), every model owns its own z slab of the grid, and no coordinate is touched, so the
-// pairs of a pack are exactly the union of the members' pairs; they are split back by the structure of `i`.
+// the path shards over independent structures, no collective.  Structures are dealt longest-first to the
+// devices; each device runs ONE host thread that drives a two-deep pipeline of PACKS on two contexts (two streams, two
+// workspaces, two pinned staging blocks):
+//
+//   assemble pack i (helper threads copy the members' arrays, untouched, straight into the pinned block)
+//   -> one H2D copy -> renumber on the device (batch.inl) -> ONE launch sequence for the whole pack -> split the joint
+//   pair list into per-member lists on the device -> D2H of the grouped list -> helper threads hand out the members' lists
+//
+// While pack i is on the device, the host assembles pack i+1 and hands out pack i-1; the copies of one stream overlap the
+// kernels of the other.  Small structures do not fill the chip (a 5k-atom structure is ~80 wave tasks for 256 CUs, and the
+// nine launches of a call cost ~100 us whatever the size), which is why they share launches at all.
 namespace {
-constexpr uint64_t kPackAtoms = 4u << 20;   // atoms per pack: ~1 GiB of pairs at 16 pairs/atom
-constexpr uint32_t kPackModels = 60000;     // model ids are u16
+constexpr uint64_t kPackAtoms = 1u << 20;    // atoms per pack: ~200 structures of 5k atoms; ~50 packs keep the pipeline full on a 10^4 batch
+constexpr uint32_t kPackMembers = 32768;     // members per pack (the device also checks that the models fit 16 bits)
 
-struct Pack {
+struct PackPlan {
     std::vector<int32_t> members;
     uint64_t n = 0, n_res = 0, n_h = 0;
-    uint32_t n_models = 0;
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool single = false;                     // not packable: goes through arp_contacts_atomic on its own
 };
 
-struct Extent {
-    double lo[3], hi[3];
-    uint32_t n_models;
-    bool packable;
+bool packable(const arp_atoms *a) {
+    if (!a || a->location != ARP_MEM_HOST || a->n == 0 || a->n_res == 0 || a->n >= kPackAtoms) return false;
+    if (!a->x || !a->y || !a->z || !a->attr || !a->res_ord || !a->chain_rank || !a->model || !a->res_id || !a->res_h_ptr || !a->res_cb || !a->res_sg) return false;
+    if (a->res_h_ptr[a->n_res] && !a->res_h_idx) return false;
+    return true;
+}
+
+// segments of a pack's block, 256-byte aligned: the twelve input arrays, the descriptor table, then device-only scratch
+struct PackLayout {
+    enum { X, Y, Z, ATTR, RES_ORD, CHAIN, MODEL, RES_ID, RES_H_PTR, RES_CB, RES_SG, RES_H_IDX, DESC, N_MODELS, STATUS, COUNT, OFFSET, CURSOR, N_SEG };
+    uint64_t off[N_SEG], upload = 0, total = 0;
+    PackLayout(uint64_t n, uint64_t nr, uint64_t nh, uint64_t K) {
+        const uint64_t bytes[N_SEG] = {n * 8, n * 8, n * 8, n * 4, n * 4, n * 2, n * 2, n * 4, (nr + 1) * 4, nr * 4, nr * 4, nh * 4, (K + 1) * 16,
+                                       K * 4, 256, K * 8, (K + 1) * 8, K * 8};
+        uint64_t t = 0;
+        for (int k = 0; k < N_SEG; k++) { off[k] = t; t += (bytes[k] + 255u) & ~255ull; if (k == DESC) upload = t; }
+        total = std::max<uint64_t>(t, 256);
+    }
 };
 
-Extent measure(const arp_atoms *a) {
-    Extent e{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}, 1, false};
-    if (!a || a->location != ARP_MEM_HOST || a->n == 0 || a->n_res == 0 || a->n >= kPackAtoms) return e;
-    if (!a->x || !a->y || !a->z || !a->attr || !a->res_ord || !a->chain_rank || !a->model || !a->res_id || !a->res_h_ptr || !a->res_cb || !a->res_sg)
-        return e;
-    if (a->res_h_ptr[a->n_res] && !a->res_h_idx) return e;
-    uint32_t mm = 0;
-    for (uint64_t i = 0; i < a->n; i++) {
-        const double p[3] = {a->x[i], a->y[i], a->z[i]};
-        for (int k = 0; k < 3; k++) {
-            if (!std::isfinite(p[k])) return e;  // the single-structure path reports it
-            e.lo[k] = std::min(e.lo[k], p[k]);
-            e.hi[k] = std::max(e.hi[k], p[k]);
-        }
-        mm = std::max<uint32_t>(mm, a->model[i]);
-    }
-    e.n_models = mm + 1;
-    e.packable = true;
-    return e;
+template <class F>
+void run_helpers(int helpers, size_t n, F &&fn) {  // fn(item) over [0, n) on up to `helpers` threads (dynamic: items differ in size)
+    if (helpers <= 1 || n <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(k); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < helpers; t++) try { th.emplace_back(work); } catch (const std::system_error &) { break; }
+    work();
+    for (auto &t : th) t.join();
 }
 
-// cells the shared grid would need (grid.inl grid_setup) against what the workspace gives a pack of n atoms
-bool grid_fits(const double lo[3], const double hi[3], uint32_t n_models, uint64_t n, double cutoff) {
-    const double edge = std::max(cutoff * (1.0 + 1e-6), 1e-3);
-    double cells = (double)n_models;
-    for (int k = 0; k < 3; k++) cells *= std::floor((hi[k] - lo[k]) / edge) + 1.0 + (k == 2 ? 1.0 : 0.0);
-    return cells <= 8.0 * (double)n;
+struct BatchSlot {
+    arp_context *ctx = nullptr;
+    bool owned = false;
+    PackPlan plan;
+    bool in_flight = false;
+    std::vector<uint64_t> first_atom;        // per member (+ sentinel): offsets inside the pack
+    PackArrays pa{};
+    DevAtoms dev{};
+    bool ordered = false;
+};
+
+arp_status ensure_pack_buffers(arp_context *ctx, uint64_t in_bytes, uint64_t out_records, uint64_t K) {
+    auto &s = ctx->st;
+    if (s.bytes < in_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.pinned) (void)hipHostFree(s.pinned);
+        s = arp_context::Staged{};
+        const uint64_t cap = in_bytes + in_bytes / 4;
+        HIP_TRY(hipMalloc((void **)&s.dev, cap));
+        HIP_TRY(hipHostMalloc((void **)&s.pinned, cap, hipHostMallocDefault));
+        s.bytes = cap;
+    }
+    if (ctx->out_cap < out_records || ctx->grp_cap < out_records) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+        if (ctx->grp_buf) (void)hipFree(ctx->grp_buf);
+        if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
+        ctx->out_buf = ctx->grp_buf = nullptr; ctx->out_pinned = nullptr; ctx->out_cap = ctx->grp_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->out_buf, out_records * sizeof(arp_pair)));
+        ctx->out_cap = out_records;
+        HIP_TRY(hipMalloc((void **)&ctx->grp_buf, out_records * sizeof(arp_pair)));
+        HIP_TRY(hipHostMalloc((void **)&ctx->out_pinned, out_records * sizeof(arp_pair), hipHostMallocDefault));
+        ctx->grp_cap = out_records;
+    }
+    if (ctx->h_offsets_cap < K + 4) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
+        ctx->h_offsets = nullptr; ctx->h_offsets_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_offsets, (K + 4 + K / 4) * sizeof(unsigned long long), hipHostMallocDefault));
+        ctx->h_offsets_cap = K + 4 + K / 4;
+    }
+    return ARP_OK;
 }
 
-arp_status run_pack(arp_context *ctx, const Pack &pk, const arp_atoms *const *atoms, const arp_params *params, arp_pairs *outs) {
-    const size_t K = pk.members.size();
-    std::vector<double> x(pk.n), y(pk.n), z(pk.n);
-    std::vector<uint32_t> attr(pk.n), res_ord(pk.n), res_id(pk.n), res_h_ptr(pk.n_res + 1), res_h_idx(pk.n_h), res_cb(pk.n_res), res_sg(pk.n_res);
-    std::vector<uint16_t> chain_rank(pk.n), model(pk.n);
-    std::vector<uint64_t> first(K + 1, 0);
-    uint64_t o = 0, ro = 0, ho = 0;
-    uint32_t mo = 0;
-    for (size_t m = 0; m < K; m++) {
-        const arp_atoms &a = *atoms[pk.members[m]];
-        first[m] = o;
-        memcpy(&x[o], a.x, a.n * 8); memcpy(&y[o], a.y, a.n * 8); memcpy(&z[o], a.z, a.n * 8);
-        memcpy(&attr[o], a.attr, a.n * 4); memcpy(&res_ord[o], a.res_ord, a.n * 4); memcpy(&chain_rank[o], a.chain_rank, a.n * 2);
-        uint32_t mm = 0;
-        for (uint64_t i = 0; i < a.n; i++) {
-            mm = std::max<uint32_t>(mm, a.model[i]);
-            model[o + i] = (uint16_t)(mo + a.model[i]);
-            res_id[o + i] = (uint32_t)(ro + a.res_id[i]);
-        }
-        const uint64_t nh = a.res_h_ptr[a.n_res];
-        for (uint64_t r = 0; r < a.n_res; r++) {
-            res_h_ptr[ro + r] = (uint32_t)(ho + a.res_h_ptr[r]);
-            res_cb[ro + r] = a.res_cb[r] == ARP_NONE ? ARP_NONE : (uint32_t)(o + a.res_cb[r]);
-            res_sg[ro + r] = a.res_sg[r] == ARP_NONE ? ARP_NONE : (uint32_t)(o + a.res_sg[r]);
-        }
-        for (uint64_t h = 0; h < nh; h++) res_h_idx[ho + h] = (uint32_t)(o + a.res_h_idx[h]);
-        o += a.n; ro += a.n_res; ho += nh; mo += mm + 1;
+// steps 4-6 of a pack: grid + pair kernels + split + the small D2H of counts (everything asynchronous on the slot's stream)
+arp_status enqueue_pack_kernels(BatchSlot &sl, const arp_params *params) {
+    arp_context *ctx = sl.ctx;
+    const bool only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
+    Profiler *prof = nullptr;
+    launch_grid(sl.dev, ctx->ws, ctx->stream, prof, params->dist_cutoff, sl.ordered);
+    if (sl.ordered) {
+        launch_count(sl.dev, ctx->ws, ctx->stream, prof, ctx->out_cap, true, only);
+        launch_fill_ordered(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only);
+    } else {
+        launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only);
     }
-    first[K] = o;
-    res_h_ptr[ro] = (uint32_t)ho;
-    arp_atoms all{};
-    all.n = o; all.x = x.data(); all.y = y.data(); all.z = z.data(); all.attr = attr.data(); all.res_ord = res_ord.data();
-    all.chain_rank = chain_rank.data(); all.model = model.data(); all.res_id = res_id.data(); all.n_res = ro;
-    all.res_h_ptr = res_h_ptr.data(); all.res_h_idx = res_h_idx.data(); all.res_cb = res_cb.data(); all.res_sg = res_sg.data();
-    all.location = ARP_MEM_HOST;
-    arp_pairs joint{};
-    arp_status s = arp_contacts_atomic(ctx, &all, params, ARP_MEM_HOST, &joint);
+    launch_pack_split(sl.pa, ctx->ws.result, ctx->out_buf, ctx->grp_buf, sl.ordered, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_offsets, sl.pa.offset, (sl.pa.K + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_offsets + sl.pa.K + 1, sl.pa.status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return ARP_OK;
+}
+
+arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_params *params, int helpers) {
+    arp_context *ctx = sl.ctx;
+    const PackPlan &pk = sl.plan;
+    const uint64_t K = pk.members.size();
+    arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
-    // split by the structure of i, keeping the emitted order inside every structure
-    std::vector<uint32_t> owner(o);
-    for (size_t m = 0; m < K; m++) std::fill(owner.begin() + first[m], owner.begin() + first[m + 1], (uint32_t)m);
-    std::vector<uint64_t> count(K, 0);
-    for (uint64_t p = 0; p < joint.n; p++) count[owner[joint.data[p].i]]++;
-    for (size_t m = 0; m < K; m++) {
-        arp_pairs &out = outs[pk.members[m]];
-        out.n = count[m]; out.location = ARP_MEM_HOST; out.data = nullptr;
-        if (count[m] && !(out.data = (arp_pair *)malloc(count[m] * sizeof(arp_pair)))) {
-            for (size_t q = 0; q < m; q++) arp_pairs_free(&outs[pk.members[q]]);
-            arp_pairs_free(&joint);
-            set_error("out of host memory");
-            return ARP_ERR_OOM;
+    if ((s = ensure_workspace(ctx, pk.n)) != ARP_OK) return s;
+    const PackLayout lay(pk.n, pk.n_res, pk.n_h, K);
+    // output guess: contacts-only lists hold ~1 record per atom, full candidate lists ~15-30; a pack that needs more is re-run (finalize)
+    const bool only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
+    const uint64_t guess = std::max<uint64_t>((only ? 4u : 32u) * pk.n, 1u << 16);
+    if ((s = ensure_pack_buffers(ctx, lay.total, std::max(guess, ctx->out_cap), K)) != ARP_OK) return s;
+    char *pin = ctx->st.pinned, *dev = ctx->st.dev;
+    // member offsets (serial: three running sums), then the copies -- the only per-atom host work of the batch path
+    sl.first_atom.assign(K + 1, 0);
+    PackDesc *desc = reinterpret_cast<PackDesc *>(pin + lay.off[PackLayout::DESC]);
+    {
+        uint64_t o = 0, ro = 0, ho = 0;
+        for (uint64_t m = 0; m < K; m++) {
+            const arp_atoms &a = *atoms[pk.members[m]];
+            desc[m] = PackDesc{(uint32_t)o, (uint32_t)ro, (uint32_t)ho, 0u};
+            sl.first_atom[m] = o;
+            o += a.n; ro += a.n_res; ho += a.res_h_ptr[a.n_res];
         }
-        count[m] = 0;
+        desc[K] = PackDesc{(uint32_t)o, (uint32_t)ro, (uint32_t)ho, 0u};
+        sl.first_atom[K] = o;
     }
-    for (uint64_t p = 0; p < joint.n; p++) {
-        arp_pair q = joint.data[p];
-        const uint32_t m = owner[q.i];
-        q.i -= (uint32_t)first[m]; q.j -= (uint32_t)first[m];
-        outs[pk.members[m]].data[count[m]++] = q;
+    auto seg = [&](int k) { return pin + lay.off[k]; };
+    run_helpers(helpers, (size_t)K, [&](size_t m) {
+        const arp_atoms &a = *atoms[pk.members[m]];
+        const PackDesc d = desc[m];
+        const uint64_t nh = a.res_h_ptr[a.n_res];
+        memcpy(seg(PackLayout::X) + 8ull * d.first_atom, a.x, a.n * 8); memcpy(seg(PackLayout::Y) + 8ull * d.first_atom, a.y, a.n * 8);
+        memcpy(seg(PackLayout::Z) + 8ull * d.first_atom, a.z, a.n * 8);
+        memcpy(seg(PackLayout::ATTR) + 4ull * d.first_atom, a.attr, a.n * 4); memcpy(seg(PackLayout::RES_ORD) + 4ull * d.first_atom, a.res_ord, a.n * 4);
+        memcpy(seg(PackLayout::CHAIN) + 2ull * d.first_atom, a.chain_rank, a.n * 2); memcpy(seg(PackLayout::MODEL) + 2ull * d.first_atom, a.model, a.n * 2);
+        memcpy(seg(PackLayout::RES_ID) + 4ull * d.first_atom, a.res_id, a.n * 4);
+        memcpy(seg(PackLayout::RES_H_PTR) + 4ull * d.first_res, a.res_h_ptr, a.n_res * 4);
+        memcpy(seg(PackLayout::RES_CB) + 4ull * d.first_res, a.res_cb, a.n_res * 4); memcpy(seg(PackLayout::RES_SG) + 4ull * d.first_res, a.res_sg, a.n_res * 4);
+        if (nh) memcpy(seg(PackLayout::RES_H_IDX) + 4ull * d.first_h, a.res_h_idx, nh * 4);
+    });
+    HIP_TRY(hipMemcpyAsync(dev, pin, lay.upload, hipMemcpyHostToDevice, ctx->stream));
+    auto at = [&](int k) { return dev + lay.off[k]; };
+    PackArrays &pa = sl.pa;
+    pa.n = (uint32_t)pk.n; pa.n_res = (uint32_t)pk.n_res; pa.n_h = (uint32_t)pk.n_h; pa.K = (uint32_t)K;
+    pa.desc = (PackDesc *)at(PackLayout::DESC); pa.model = (uint16_t *)at(PackLayout::MODEL); pa.res_id = (uint32_t *)at(PackLayout::RES_ID);
+    pa.res_h_ptr = (uint32_t *)at(PackLayout::RES_H_PTR); pa.res_cb = (uint32_t *)at(PackLayout::RES_CB); pa.res_sg = (uint32_t *)at(PackLayout::RES_SG);
+    pa.res_h_idx = (uint32_t *)at(PackLayout::RES_H_IDX); pa.n_models = (uint32_t *)at(PackLayout::N_MODELS); pa.status = (uint32_t *)at(PackLayout::STATUS);
+    pa.count = (unsigned long long *)at(PackLayout::COUNT); pa.offset = (unsigned long long *)at(PackLayout::OFFSET); pa.cursor = (unsigned long long *)at(PackLayout::CURSOR);
+    launch_pack_fix(pa, ctx->stream);
+    DevAtoms &d = sl.dev;
+    d = DevAtoms{};
+    d.n = pa.n; d.n_res = pa.n_res; d.per_model = 1u;
+    d.x = (const double *)at(PackLayout::X); d.y = (const double *)at(PackLayout::Y); d.z = (const double *)at(PackLayout::Z);
+    d.attr = (const uint32_t *)at(PackLayout::ATTR); d.res_ord = (const uint32_t *)at(PackLayout::RES_ORD);
+    d.chain_rank = (const uint16_t *)at(PackLayout::CHAIN); d.model = pa.model;
+    d.res_id = pa.res_id; d.res_h_ptr = pa.res_h_ptr; d.res_h_idx = pa.res_h_idx; d.res_cb = pa.res_cb; d.res_sg = pa.res_sg;
+    sl.ordered = false;  // (ordered calls are never packed, see the plan)
+    if ((s = upload_params(ctx, params)) != ARP_OK) return s;
+    if ((s = enqueue_pack_kernels(sl, params)) != ARP_OK) return s;
+    sl.in_flight = true;
+    return ARP_OK;
+}
+
+// wait for a pack, fetch the grouped list, hand the members their lists.  An input error inside the pack (or more models than 16
+// bits hold) is re-run member by member so that the failing structure reports it.
+arp_status finalize_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_params *params, arp_pairs *outs, int helpers) {
+    if (!sl.in_flight) return ARP_OK;
+    sl.in_flight = false;
+    arp_context *ctx = sl.ctx;
+    const PackPlan &pk = sl.plan;
+    const uint64_t K = pk.members.size();
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    unsigned long long total = 0;
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const uint32_t pack_status = *reinterpret_cast<const uint32_t *>(ctx->h_offsets + K + 1);
+        s = flags_to_status(ctx->h_result[1]);
+        if (s == kRetryDefer && attempt < 4) {  // deferred-probe list too small: grow it, run the pack's kernels again
+            if ((s = grow_defer_list(ctx, pk.n)) != ARP_OK) return s;
+            if ((s = upload_params(ctx, params)) != ARP_OK || (s = enqueue_pack_kernels(sl, params)) != ARP_OK) return s;
+            continue;
+        }
+        if (s != ARP_OK || pack_status != 0u) {
+            for (int32_t k : pk.members)
+                if ((s = arp_contacts_atomic(ctx, atoms[k], params, ARP_MEM_HOST, &outs[k])) != ARP_OK) return s;
+            return ARP_OK;
+        }
+        total = ctx->h_result[0];
+        if (total <= ctx->out_cap) break;
+        if (attempt >= 4) { set_error("internal error: pair count changed between passes"); return ARP_ERR_HIP; }
+        const PackLayout lay(pk.n, pk.n_res, pk.n_h, K);
+        if ((s = ensure_pack_buffers(ctx, lay.total, total + total / 8, K)) != ARP_OK) return s;  // (the staged inputs stay where they are)
+        if ((s = upload_params(ctx, params)) != ARP_OK || (s = enqueue_pack_kernels(sl, params)) != ARP_OK) return s;
     }
-    arp_pairs_free(&joint);
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(ctx->out_pinned, ctx->grp_buf, total * sizeof(arp_pair), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    const unsigned long long *off = ctx->h_offsets;
+    const arp_pair *all = reinterpret_cast<const arp_pair *>(ctx->out_pinned);
+    std::atomic<bool> oom{false};
+    run_helpers(helpers, (size_t)K, [&](size_t m) {
+        arp_pairs &out = outs[pk.members[m]];
+        const unsigned long long cnt = off[m + 1] - off[m];
+        out.n = cnt; out.location = ARP_MEM_HOST; out.data = nullptr;
+        if (!cnt) return;
+        out.data = (arp_pair *)malloc(cnt * sizeof(arp_pair));
+        if (!out.data) { out.n = 0; oom = true; return; }
+        memcpy(out.data, all + off[m], cnt * sizeof(arp_pair));
+    });
+    if (oom) { set_error("out of host memory"); return ARP_ERR_OOM; }
     return ARP_OK;
 }
 }  // namespace
 
-// One host thread + one context (stream) per device, longest-processing-time-first deal, packed launches per device.
 extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms, int32_t n_structures,
                                                 const arp_params *params, arp_pairs *outs) {
     if (!ctxs || n_ctx <= 0 || !atoms || n_structures < 0 || !outs || !params) { set_error("bad batch arguments"); return ARP_ERR_BAD_INPUT; }
     for (int32_t k = 0; k < n_structures; k++) outs[k] = arp_pairs{0, nullptr, ARP_MEM_HOST, 0};
+    for (int32_t k = 0; k < n_structures; k++)
+        if (!atoms[k]) { set_error("null structure %d in the batch", k); return ARP_ERR_BAD_INPUT; }
+    for (int d = 0; d < n_ctx; d++)
+        if (!ctxs[d]) { set_error("null context %d in the batch", d); return ARP_ERR_BAD_INPUT; }
+    // longest-processing-time-first deal over the devices (the same rule as arpeggia_amd/sharding.py)
     std::vector<int32_t> order(n_structures);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return atoms[a]->n > atoms[b]->n; });
@@ -676,54 +809,72 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
         queue[best].push_back(k);
         load[best] += atoms[k]->n + 1;
     }
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int helpers = std::max(1, std::min(8, hw / std::max(1, n_ctx)));
     std::vector<arp_status> st(n_ctx, ARP_OK);
     std::vector<std::string> msg(n_ctx);
-    std::vector<std::thread> th;
-    for (int d = 0; d < n_ctx; d++)
-        th.emplace_back([&, d]() {
-            auto fail = [&](arp_status s) { st[d] = s; msg[d] = arp_last_error(); };
-            auto run_single = [&](int32_t k) { return arp_contacts_atomic(ctxs[d], atoms[k], params, ARP_MEM_HOST, &outs[k]); };
-            auto flush = [&](Pack &pk) {
-                arp_status s = ARP_OK;
-                if (pk.members.size() == 1) s = run_single(pk.members[0]);
-                else if (pk.members.size() > 1 && (s = run_pack(ctxs[d], pk, atoms, params, outs)) != ARP_OK && s != ARP_ERR_OOM && s != ARP_ERR_HIP) {
-                    // an input error inside the pack: rerun the members one by one so that the failing structure reports it
-                    s = ARP_OK;
-                    for (int32_t k : pk.members)
-                        if ((s = run_single(k)) != ARP_OK) break;
-                }
-                pk = Pack{};
-                return s;
-            };
-            Pack pk;
+    auto device_worker = [&](int d) {
+        auto fail = [&](arp_status s) { st[d] = s; msg[d] = arp_last_error(); };
+        // plan: consecutive members of the device's share form packs; what cannot be packed runs alone
+        std::vector<PackPlan> plans;
+        {
+            PackPlan cur;
+            auto close = [&]() { if (!cur.members.empty()) plans.push_back(std::move(cur)); cur = PackPlan{}; };
             for (int32_t k : queue[d]) {
-                // Packing pays when the launch overhead dominates, i.e. for the small contacts-only lists; full candidate lists are
-                // bound by the copy to the host, which a pack would only add a second (splitting) pass to.
-                Extent e = measure(atoms[k]);
-                if (!(params->flags & ARP_FLAG_CONTACTS_ONLY)) e.packable = false;
-                arp_status s = ARP_OK;
-                if (!e.packable) {
-                    if ((s = flush(pk)) != ARP_OK || (s = run_single(k)) != ARP_OK) return fail(s);
+                const arp_atoms *a = atoms[k];
+                // The ordered emitter's promise (output byte-identical run to run) cannot be kept through a pack: its records are laid
+                // out task by task, and the task that straddles two members interleaves their records.  Ordered calls go one by one.
+                if (!packable(a) || (params->flags & ARP_FLAG_DETERMINISTIC)) {
+                    close();
+                    PackPlan one; one.members.push_back(k); one.single = true; plans.push_back(std::move(one));
                     continue;
                 }
-                const arp_atoms &a = *atoms[k];
-                double lo[3], hi[3];
-                for (int c = 0; c < 3; c++) { lo[c] = std::min(pk.lo[c], e.lo[c]); hi[c] = std::max(pk.hi[c], e.hi[c]); }
-                if (!pk.members.empty() && (pk.n + a.n > kPackAtoms || pk.n_models + e.n_models > kPackModels ||
-                                            !grid_fits(lo, hi, pk.n_models + e.n_models, pk.n + a.n, params->dist_cutoff))) {
-                    if ((s = flush(pk)) != ARP_OK) return fail(s);
-                    for (int c = 0; c < 3; c++) { lo[c] = e.lo[c]; hi[c] = e.hi[c]; }
-                }
-                pk.members.push_back(k);
-                pk.n += a.n; pk.n_res += a.n_res; pk.n_h += a.res_h_ptr[a.n_res]; pk.n_models += e.n_models;
-                for (int c = 0; c < 3; c++) { pk.lo[c] = lo[c]; pk.hi[c] = hi[c]; }
+                if (!cur.members.empty() && (cur.n + a->n > kPackAtoms || cur.members.size() >= kPackMembers)) close();
+                cur.members.push_back(k);
+                cur.n += a->n; cur.n_res += a->n_res; cur.n_h += a->res_h_ptr[a->n_res];
             }
-            arp_status s = flush(pk);
-            if (s != ARP_OK) fail(s);
-        });
+            close();
+            for (PackPlan &p : plans) if (!p.single && p.members.size() == 1) p.single = true;  // nothing to share a launch with
+        }
+        BatchSlot slot[2];
+        slot[0].ctx = ctxs[d];
+        auto cleanup = [&]() { if (slot[1].owned && slot[1].ctx) arp_context_destroy(slot[1].ctx); };
+        arp_status s = ARP_OK;
+        const size_t np = plans.size();
+        for (size_t i = 0; i <= np && s == ARP_OK; i++) {
+            if (i < np) {
+                if (plans[i].single) {  // synchronous: drain the pipeline first (it uses both contexts)
+                    for (int q = 0; q < 2 && s == ARP_OK; q++) s = finalize_pack(slot[(i + q) & 1], atoms, params, outs, helpers);
+                    if (s == ARP_OK) s = arp_contacts_atomic(ctxs[d], atoms[plans[i].members[0]], params, ARP_MEM_HOST, &outs[plans[i].members[0]]);
+                    continue;
+                }
+                BatchSlot &sl = slot[i & 1];
+                if (!sl.ctx) {  // the second context of the device: same device, its own stream and workspace
+                    if ((s = arp_context_create(ctxs[d]->device, &sl.ctx)) != ARP_OK) break;
+                    sl.owned = true;
+                }
+                sl.plan = std::move(plans[i]);
+                if ((s = launch_pack(sl, atoms, params, helpers)) != ARP_OK) break;
+            }
+            if (i >= 1 && !(i - 1 < np && plans[i - 1].single)) s = finalize_pack(slot[(i - 1) & 1], atoms, params, outs, helpers);
+        }
+        if (s != ARP_OK) {
+            fail(s);
+            for (int q = 0; q < 2; q++) if (slot[q].ctx) (void)hipStreamSynchronize(slot[q].ctx->stream);
+        }
+        cleanup();
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < n_ctx; d++)
+        try { th.emplace_back(device_worker, d); } catch (const std::system_error &) { device_worker(d); }  // no thread: this device's share runs here
+    device_worker(0);
     for (auto &t : th) t.join();
     for (int d = 0; d < n_ctx; d++)
-        if (st[d] != ARP_OK) { set_error("%s", msg[d].c_str()); return st[d]; }
+        if (st[d] != ARP_OK) {
+            for (int32_t k = 0; k < n_structures; k++) arp_pairs_free(&outs[k]);
+            set_error("%s", msg[d].c_str());
+            return st[d];
+        }
     return ARP_OK;
 }
 

@@ -122,8 +122,35 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
     }
 }
 
+// Packed batches: bounding box PER MODEL, as order-preserving codes of f32 values rounded outwards (the box only has to contain
+// the atoms).  The members of a pack are contiguous, so a wave is almost always inside one model: six wave reductions, six atomics.
+DEVFN uint32_t f32_code(float f) { const uint32_t u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
+DEVFN float f32_decode(uint32_t c) { return __uint_as_float((c >> 31) ? (c & 0x7FFFFFFFu) : ~c); }
+__global__ __launch_bounds__(256) void k_model_box_init(uint32_t *box) {  // {min xyz = +inf code, max xyz = -inf code} per model
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    box[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u;
+}
+__global__ __launch_bounds__(256) void k_model_bounds(DevAtoms in, uint32_t *box) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool use = i < in.n && !(in.attr[i] & ARP_ATTR_H);
+    uint32_t m = ARP_NONE, lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    if (use) {
+        m = in.model[i];
+        const double p[3] = {in.x[i], in.y[i], in.z[i]};
+        for (int k = 0; k < 3; k++) { lo[k] = f32_code(__double2float_rd(p[k])); hi[k] = f32_code(__double2float_ru(p[k])); }
+    }
+    const uint32_t first = wave_min_u32(m);
+    if (first == ARP_NONE) return;
+    if (__all(m == first || m == ARP_NONE)) {
+        for (int k = 0; k < 3; k++) { lo[k] = wave_min_u32(lo[k]); hi[k] = wave_max_u32(hi[k]); }
+        if (lane == 0) for (int k = 0; k < 3; k++) { atomicMin(&box[6u * first + k], lo[k]); atomicMax(&box[6u * first + 3 + k], hi[k]); }
+    } else if (use) {
+        for (int k = 0; k < 3; k++) { atomicMin(&box[6u * m + k], lo[k]); atomicMax(&box[6u * m + 3 + k], hi[k]); }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t n_partials, GridParams *g, DevParams *prm, double cutoff,
-                                               uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr) {
+                                               uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr, const uint32_t *model_box, double *model_org) {
     __shared__ double s_mn[4][3], s_mx[4][3];
     __shared__ uint32_t s_models[4], s_bad[4];
     for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
@@ -151,14 +178,44 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
             if (b < prm->r2) { prm->r2 = b; cutoff = sqrt(b); }
         }
     }
-    if (threadIdx.x == 0) {
+    // Packed batch: the grid is sized by the LARGEST member and every model gets its own origin (its box's min corner) and
+    // its own midpoint for the f32 records -- members may sit anywhere in space without inflating the cell count.
+    __shared__ double s_ext[4][3];
+    if (model_box) {
+        double ext[3] = {0.0, 0.0, 0.0};  // (differences of f32 values are exact in f64)
+        for (uint32_t m = threadIdx.x; m < acc.models; m += blockDim.x) {
+            const uint32_t *b = model_box + 6u * m;
+            if (b[0] == 0xFFFFFFFFu) continue;  // no heavy atom in this model
+            for (int k = 0; k < 3; k++) ext[k] = fmax(ext[k], (double)f32_decode(b[3 + k]) - (double)f32_decode(b[k]));
+        }
+        for (int off = 32; off; off >>= 1) for (int k = 0; k < 3; k++) ext[k] = fmax(ext[k], __shfl_xor(ext[k], off));
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; k++) s_ext[threadIdx.x >> 6][k] = ext[k];
+        __syncthreads();
+        for (int k = 0; k < 3; k++) ext[k] = fmax(fmax(s_ext[0][k], s_ext[1][k]), fmax(s_ext[2][k], s_ext[3][k]));
+        for (uint32_t m = threadIdx.x; m < acc.models; m += blockDim.x) {
+            const uint32_t *b = model_box + 6u * m;
+            double *o = model_org + 6u * m;
+            for (int k = 0; k < 3; k++) {
+                const double lo = b[0] == 0xFFFFFFFFu ? 0.0 : (double)f32_decode(b[k]);
+                o[k] = lo; o[3 + k] = lo + 0.5 * ext[k];
+            }
+        }
+        if (threadIdx.x == 0) {
+            const double zero[3] = {0.0, 0.0, 0.0}, hi[3] = {ext[0], ext[1], ext[2]};
+            grid_setup(zero, hi, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap);
+            g->model_org = model_org;
+        }
+    } else if (threadIdx.x == 0) {
         grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap);
-        g->all_both = (acc.bad >> 24) & 1u ? 0u : 1u;
+        g->model_org = nullptr;
     }
+    if (threadIdx.x == 0) g->all_both = (acc.bad >> 24) & 1u ? 0u : 1u;
 }
 
 DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
-    double fx = (x - g.ox) * g.inv_edge, fy = (y - g.oy) * g.inv_edge, fz = (z - g.oz) * g.inv_edge;
+    double ox = g.ox, oy = g.oy, oz = g.oz;
+    if (g.model_org) { const double *o = g.model_org + 6u * model; ox = o[0]; oy = o[1]; oz = o[2]; }  // packed batch: the member's own corner
+    double fx = (x - ox) * g.inv_edge, fy = (y - oy) * g.inv_edge, fz = (z - oz) * g.inv_edge;
     uint32_t cx = (fx >= 0.0) ? (uint32_t)fmin(fx, 4.0e9) : 0u;  // NaN -> 0
     uint32_t cy = (fy >= 0.0) ? (uint32_t)fmin(fy, 4.0e9) : 0u;
     uint32_t cz = (fz >= 0.0) ? (uint32_t)fmin(fz, 4.0e9) : 0u;
@@ -300,7 +357,9 @@ DEVFN uint32_t make_pair_word(uint32_t attr, bool res_has_h) {
 
 DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so, uint32_t i, uint32_t c, uint32_t d) {
     const double x = in.x[i], y = in.y[i], z = in.z[i];
-    const float fx = (float)(x - gp->mx), fy = (float)(y - gp->my), fz = (float)(z - gp->mz);
+    double mx = gp->mx, my = gp->my, mz = gp->mz;
+    if (gp->model_org) { const double *o = gp->model_org + 6u * (uint32_t)in.model[i] + 3u; mx = o[0]; my = o[1]; mz = o[2]; }
+    const float fx = (float)(x - mx), fy = (float)(y - my), fz = (float)(z - mz);
     so.rec[d] = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
     // "the residue carries hydrogens" as a bit of the record: the hot kernel never touches the hydrogen tables, the deferred
     // pass resolves residue -> hydrogens itself (hbond.rs:38-42)

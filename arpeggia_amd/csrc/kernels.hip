@@ -7,6 +7,7 @@
 // (src/contacts/complex.rs:189-299) with a uniform-grid cell list and a count/scan/fill pair emitter whose
 // output order is deterministic.  Decisions are made in f64 with the reference's operation order and no FMA
 // contraction (this file is compiled with -ffp-contract=off); an f32 test with a proven margin only prefilters.
+#include <algorithm>
 #include <cstdlib>
 
 #include "arp_internal.h"
@@ -260,5 +261,6 @@ DEVFN float dist_f32(double s) {
 // ---------------------------------------------------------------------------------------------- pair search + launch
 #include "pairs.inl"
 #include "pairs_lds.inl"
+#include "batch.inl"
 
 }  // namespace arp

@@ -620,8 +620,12 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
     P0("grid_bounds");
     const uint32_t bb = nb < 1 ? 1 : (nb < kBoundsBlocks ? nb : kBoundsBlocks);
     hipLaunchKernelGGL(k_bounds, dim3(bb), dim3(256), 0, st, in, ws.partials);
+    if (in.per_model && n) {
+        hipLaunchKernelGGL(k_model_box_init, dim3(65536u * 6u / 256u), dim3(256), 0, st, ws.model_box);
+        hipLaunchKernelGGL(k_model_bounds, dim3(nb), dim3(256), 0, st, in, ws.model_box);
+    }
     hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, (const double *)ws.partials, bb, ws.grid, ws.params, cutoff, ws.ncells_cap, ws.result,
-                       ws.task_ctr);
+                       ws.task_ctr, in.per_model ? (const uint32_t *)ws.model_box : (const uint32_t *)nullptr, ws.model_org);
     P1();
     P0("grid_count");
     if (n) hipLaunchKernelGGL(k_cellid, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
