@@ -112,6 +112,7 @@ struct arp_context {
     bool have_params = false;
     uint64_t last_capacity = 0;
     bool pending = false;
+    arp_context *peer = nullptr;           // batch path: the second context of this device (own stream + workspace), kept across calls
     uint32_t defer_scale = 1;              // the deferred-probe list is sized defer_scale x the default; grown on overflow
     arp_atoms last_atoms{};                // the enqueued call, kept so that arp_contacts_atomic_result can re-run it after growing a list
     arp_pair *last_out = nullptr;
@@ -212,6 +213,7 @@ static void free_staged(arp_context *ctx) {
 
 extern "C" void arp_context_destroy(arp_context *ctx) {
     if (!ctx) return;
+    if (ctx->peer) { arp_context_destroy(ctx->peer); ctx->peer = nullptr; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_workspace(ctx);
@@ -610,7 +612,6 @@ void run_helpers(int helpers, size_t n, F &&fn) {  // fn(item) over [0, n) on up
 
 struct BatchSlot {
     arp_context *ctx = nullptr;
-    bool owned = false;
     PackPlan plan;
     bool in_flight = false;
     std::vector<uint64_t> first_atom;        // per member (+ sentinel): offsets inside the pack
@@ -838,7 +839,6 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
         }
         BatchSlot slot[2];
         slot[0].ctx = ctxs[d];
-        auto cleanup = [&]() { if (slot[1].owned && slot[1].ctx) arp_context_destroy(slot[1].ctx); };
         arp_status s = ARP_OK;
         const size_t np = plans.size();
         for (size_t i = 0; i <= np && s == ARP_OK; i++) {
@@ -849,9 +849,9 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
                     continue;
                 }
                 BatchSlot &sl = slot[i & 1];
-                if (!sl.ctx) {  // the second context of the device: same device, its own stream and workspace
-                    if ((s = arp_context_create(ctxs[d]->device, &sl.ctx)) != ARP_OK) break;
-                    sl.owned = true;
+                if (!sl.ctx) {  // the second context of the device: same device, its own stream and workspace; lives with the first
+                    if (!ctxs[d]->peer && (s = arp_context_create(ctxs[d]->device, &ctxs[d]->peer)) != ARP_OK) break;
+                    sl.ctx = ctxs[d]->peer;
                 }
                 sl.plan = std::move(plans[i]);
                 if ((s = launch_pack(sl, atoms, params, helpers)) != ARP_OK) break;
@@ -862,7 +862,6 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
             fail(s);
             for (int q = 0; q < 2; q++) if (slot[q].ctx) (void)hipStreamSynchronize(slot[q].ctx->stream);
         }
-        cleanup();
     };
     std::vector<std::thread> th;
     for (int d = 1; d < n_ctx; d++)

@@ -2,19 +2,27 @@
 """bench.py -- classified atom-pairs/s of the contacts hot path on MI355X (BASELINE.json metric).
 
 One "step" = one full pass of the hot path (uniform-grid build + neighbour search + per-pair classification + compacted
-pair table) over one synthetic structure already resident in HBM.  Default workload = BASELINE.json configs[3]: the
-1e6-atom synthetic cloud at 6.5 A cutoff (generator S2 of SURVEY.md 8d, tests/synth.py).  With --gpus N every rank runs the
-same-sized structure (its own seed): the path shards over independent structures, there is no data-path collective, and
-torch.distributed is used only for the barrier and the max/sum of the timings ("scaling": "weak").
+pair table) over synthetic structures already resident in HBM.
 
-Prints ONE JSON line (rank 0) including `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline` (the oracle,
-timed on a bounded sample on this box's host cores; N=1 only).
+  `value`     BASELINE.json configs[3]: the 1e6-atom S2 synthetic cloud at 6.5 A cutoff (tests/synth.py).  With
+              --gpus N every rank runs its own same-sized cloud ("scaling": "weak"): the path shards over independent structures,
+              there is no data-path collective; torch.distributed only carries the barrier and the max/sum of the timings.
+  `s1`        the same pass on the chemistry-faithful S1 cloud of the same size ("the headline run reports both").
+  `batch5k`   BASELINE.json configs[4]: a batch of ~5k-atom S1 structures (atoms ~ N(5000, 500^2) clipped to [3000, 7000]), dealt
+              longest-first over the ranks (1250 per rank by default: 10^4 at 8 GPUs), each rank's share packed into one resident
+              multi-model SoA; plus, on rank 0, the host-inclusive figure of arp_contacts_atomic_batch on 512 of them (PCIe both ways).
+  `--workload batch5k` makes that batch the `value` instead (total size --structures, strong scaling over the ranks).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the context's stream) and `cpu_baseline`
+(the oracle -- this repo's C restatement, "port" -- on a bounded sample, one thread and all host threads; N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -24,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+SEED = 0xA11CE5EED00
 
 
 def parse():
@@ -32,10 +41,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--atoms", type=int, default=1_000_000)
-    ap.add_argument("--workload", choices=["s2", "s1"], default="s2")
+    ap.add_argument("--workload", choices=["s2", "s1", "batch5k"], default="s2")
+    ap.add_argument("--structures", type=int, default=0, help="batch5k: structures in the whole job (default 1250 per rank; 10000 = BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no s1 / batch5k sub-objects)")
     ap.add_argument("--cpu-sample-atoms", type=int, default=1_000_000,
-                    help="size of the CPU-baseline sample (default: the full 10^6-atom workload, ~10 s on one host thread)")
+                    help="size of the one-thread CPU-baseline sample (default: the full 10^6-atom workload, ~10 s)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-check", action="store_true", help="diagnostic (ablation) builds: do not assert the pair count")
     ap.add_argument("--deterministic", action="store_true", help="two-pass ordered emitter (ARP_FLAG_DETERMINISTIC)")
@@ -57,20 +68,156 @@ def to_device(soa, torch, dev):
     return out
 
 
+def pack_soas(soas):
+    """Independent structures as ONE multi-model SoA (what a packed batch looks like once resident): models renumbered to be
+    distinct, residue tables offset.  The engine never pairs atoms of different models (complex.rs:96-98)."""
+    import numpy as np
+
+    none = np.uint32(0xFFFFFFFF)
+    cat = {k: [] for k in ("x", "y", "z", "attr", "res_ord", "chain_rank", "model", "res_id", "res_h_ptr", "res_cb", "res_sg", "res_h_idx")}
+    a0 = r0 = h0 = m0 = 0
+    for s in soas:
+        n, nr = len(s["x"]), len(s["res_cb"])
+        for k in ("x", "y", "z", "attr", "res_ord", "chain_rank"):
+            cat[k].append(s[k])
+        cat["model"].append((s["model"].astype(np.uint32) + m0).astype(np.uint16))
+        cat["res_id"].append(s["res_id"] + np.uint32(r0))
+        cat["res_h_ptr"].append(s["res_h_ptr"][:-1] + np.uint32(h0))
+        for k in ("res_cb", "res_sg"):
+            cat[k].append(np.where(s[k] == none, none, s[k] + np.uint32(a0)))
+        cat["res_h_idx"].append(s["res_h_idx"] + np.uint32(a0))
+        a0 += n; r0 += nr; h0 += int(s["res_h_ptr"][-1]); m0 += int(s["model"].max(initial=0)) + 1
+    assert m0 < 65536, "a pack holds at most 65535 models"
+    out = {k: np.concatenate(v) if v else np.zeros(0) for k, v in cat.items()}
+    out["res_h_ptr"] = np.concatenate([out["res_h_ptr"], np.asarray([h0], dtype=np.uint32)]).astype(np.uint32)
+    return out
+
+
+def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, profile_steps, barrier, check=True):
+    """`steps` passes over one device-resident SoA: (wall seconds over the steps, device ms per step, pairs, per-kernel ms)."""
+    dsoa = to_device(soa, torch, dev)
+    keep = []
+    atoms = aa.atoms_from_arrays(dsoa, location=_lib.ARP_MEM_DEVICE, keep=keep)
+    stream = torch.cuda.current_stream(dev)
+    ctx = aa.Context(dev_index, stream=stream.cuda_stream)
+    n_pairs = ctx.count(atoms, prm)  # size the output once (count pass), then everything is allocation-free
+    cap = max(n_pairs, 1)            # (diagnostic ablation builds may report no pairs: still run the emit path)
+    out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    for _ in range(warmup):
+        ctx.enqueue(atoms, prm, out.data_ptr(), cap)
+    got = ctx.result() if warmup else n_pairs
+    assert not check or got == n_pairs
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(steps):
+        ctx.enqueue(atoms, prm, out.data_ptr(), cap)
+    ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    got = ctx.result()
+    assert not check or got == n_pairs
+    dev_ms = ev0.elapsed_time(ev1) / steps
+    # per-kernel durations (HIP events on the same stream, separate pass so they do not perturb the timed region)
+    acc: dict = {}
+    if profile_steps:
+        ctx.profile(True)
+        for _ in range(profile_steps):
+            ctx.enqueue(atoms, prm, out.data_ptr(), cap)
+            ctx.result()
+            for k, v in ctx.profile_read().items():
+                acc[k] = acc.get(k, 0.0) + v / profile_steps
+        ctx.profile(False)
+    del out
+    return wall, dev_ms, n_pairs, acc, len(soa["x"])
+
+
+def roofline_of(n_atoms, n_pairs, acc, dev_ms, traffic=None):
+    """algorithmic bytes = 36 B per atom read once + 16 B per classified pair written."""
+    if not acc:  # --profile-steps 0 (external profiler runs): fall back to the whole device-side step
+        acc = {"pipeline": dev_ms}
+    dom = max(acc, key=acc.get)
+    alg_bytes = 36.0 * n_atoms + 16.0 * n_pairs
+    dom_ms, pipeline_ms = acc[dom], sum(acc.values())
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "algorithmic_bytes": alg_bytes, "kernel_ms": dom_ms,
+        "pipeline_ms": pipeline_ms, "pipeline_frac": alg_bytes / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "kernels_ms": acc,
+    }
+
+
+def batch5k_sizes(n_structures: int):
+    import numpy as np
+
+    rng = np.random.default_rng(SEED + 5)
+    return np.clip(np.rint(rng.normal(5000.0, 500.0, n_structures)), 3000, 7000).astype(int)
+
+
+def batch5k_share(aa, synth, sizes, mine, pool=48):
+    """SoAs of this rank's structures.  Generating 10^4 distinct structures would take minutes of numpy time per run, so `pool`
+    distinct S1 structures per rank (sizes spread over the share's size range) stand in for the rest; every one is still an
+    independent structure of its own model in the pack."""
+    import numpy as np
+
+    order = sorted(mine, key=lambda k: sizes[k])
+    picks = [order[int(round(q))] for q in np.linspace(0, len(order) - 1, min(pool, len(order)))]
+    made = {}
+    for k in picks:
+        rec = synth.gen_s1(int(sizes[k]), seed=SEED + 5 + k)
+        made[k] = aa.Structure.from_records(rec, hierarchy=True).soa("/")
+    sized = sorted(made, key=lambda k: sizes[k])
+    soas = []
+    for k in mine:  # the stand-in closest in size
+        j = min(sized, key=lambda q: abs(int(sizes[q]) - int(sizes[k])))
+        soas.append(made[j])
+    return soas
+
+
 def cpu_baseline(n_atoms: int, workload: str):
-    """The oracle ("port": this repo's C restatement, not the reference binary) on a bounded sample, one thread."""
+    """The oracle ("port": this repo's C restatement, NOT the reference binary) on bounded samples: one thread on the headline
+    cloud, then all host threads at once, each on its own independent 10^5-atom cloud (the reference's -j 0, utils.rs:8-30)."""
+    import threading
+
     import oracle_binding as ob
     import synth
 
-    rec = getattr(synth, f"gen_{workload}")(n_atoms, seed=0xBA5E)
+    gen = getattr(synth, f"gen_{workload if workload in ('s1', 's2') else 's2'}")
+    rec = gen(n_atoms, seed=0xBA5E)
     s = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True)
     t0 = time.perf_counter()
     pairs = s.atomic_contacts("/", 0.1, 6.5)
     dt = time.perf_counter() - t0
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    small = ob.Structure.from_atoms(synth.records_to_oracle(gen(100_000, seed=0xBA5E + 1), flat=True), flat=True)
+    counts = [0] * threads
+
+    def work(k):
+        counts[k] = len(small.atomic_contacts("/", 0.1, 6.5))  # (the C call releases the GIL; the structure is only read)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t1 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt_all = time.perf_counter() - t1
+    cargo = shutil.which("cargo")
+    if cargo:
+        try:
+            cargo = subprocess.run([cargo, "--version"], capture_output=True, text=True, timeout=20).stdout.strip() or cargo
+        except (OSError, subprocess.SubprocessError):
+            pass
     return {
         "value": len(pairs) / dt, "unit": "classified atom-pairs/s", "cores": 1, "kind": "port",
         "sample": f"{workload.upper()} synthetic cloud, {n_atoms} atoms -> {len(pairs)} pairs, grid search + per-pair rules, "
                   f"{dt:.1f} s on 1 of {os.cpu_count()} host threads",
+        "all_cores": {"value": sum(counts) / dt_all, "cores": threads,
+                      "sample": f"{threads} threads, each one independent 100000-atom cloud ({counts[0]} pairs), {dt_all:.1f} s"},
+        "reference_toolchain": cargo or "cargo not found on this box: the reference (Rust) cannot be built or timed here",
+        "note": "restatement CPU baseline (oracle/arp_oracle.c), not the reference binary",
     }
 
 
@@ -82,7 +229,7 @@ def main():
     import arpeggia_amd as aa
     import synth
     from arpeggia_amd import _lib
-    from arpeggia_amd.sharding import reduce_job
+    from arpeggia_amd.sharding import lpt_assign, reduce_job
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,101 +253,117 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-
-    # ---- synthetic structure of this rank (independent structures shard with no exchange) ----
-    seed = 0xA11CE5EED00 + 4 + 1000 * rank
-    rec = getattr(synth, f"gen_{args.workload}")(args.atoms, seed=seed)
-    st = aa.Structure.from_records(rec, hierarchy=True)
-    soa = st.soa("/")
-    n = len(soa["x"])
-    dsoa = to_device(soa, torch, dev)
-    keep = []
-    atoms = aa.atoms_from_arrays(dsoa, location=_lib.ARP_MEM_DEVICE, keep=keep)
-    prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only)
-    stream = torch.cuda.current_stream(dev)
-    ctx = aa.Context(dev_index, stream=stream.cuda_stream)
-
-    # size the output once (count pass), then everything is allocation-free
-    n_pairs = ctx.count(atoms, prm)
-    cap = max(n_pairs, 1)  # (diagnostic ablation builds may report no pairs: still run the emit path)
-    out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-
-    def step():
-        ctx.enqueue(atoms, prm, out.data_ptr(), cap)
-
-    for _ in range(args.warmup):
-        step()
-    got = ctx.result()
-    assert args.no_check or got == n_pairs
+    red_dev = "cpu" if rehearse else dev
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    got = ctx.result()
-    assert args.no_check or got == n_pairs
-    dev_ms = ev0.elapsed_time(ev1)
+    prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only)
+    check = not args.no_check
 
-    # ---- per-kernel durations (HIP events on the same stream, separate pass so they do not perturb the timed region) ----
-    ctx.profile(True)
-    acc: dict = {}
-    for _ in range(args.profile_steps):
-        step()
-        ctx.result()
-        for k, v in ctx.profile_read().items():
-            acc[k] = acc.get(k, 0.0) + v / args.profile_steps
-    ctx.profile(False)
+    def cloud(workload):  # one structure per rank, its own seed: independent structures shard with no exchange
+        rec = getattr(synth, f"gen_{workload}")(args.atoms, seed=SEED + (4 if workload == "s2" else 3) + 1000 * rank)
+        return aa.Structure.from_records(rec, hierarchy=True).soa("/")
 
-    wall_max, pairs_all = reduce_job(dist, "cpu" if rehearse else dev, wall, n_pairs)  # max over ranks / sum over ranks; no data-path collective
+    def batch(total):  # this rank's longest-first share of the batch, as one resident pack (packs of <= 65535 models)
+        sizes = batch5k_sizes(total)
+        mine = lpt_assign([int(v) for v in sizes], world)[rank]
+        soas = batch5k_share(aa, synth, sizes, mine)
+        packs = [pack_soas(soas[k:k + 60000]) for k in range(0, len(soas), 60000)]
+        return packs, len(mine)
+
+    sub = {}
+    if args.workload == "batch5k":
+        total = args.structures or 1250 * world
+        packs, n_mine = batch(total)
+        wall = dev_ms = 0.0
+        n_pairs = n_atoms = 0
+        acc: dict = {}
+        for p in packs:  # (one pack unless a rank holds more than 60000 structures)
+            w, d, npair, a, na = measure_resident(aa, _lib, torch, dev, dev_index, p, prm, args.steps, args.warmup, args.profile_steps, barrier, check)
+            wall += w; dev_ms += d; n_pairs += npair; n_atoms += na
+            for k, v in a.items():
+                acc[k] = acc.get(k, 0.0) + v
+        label = f"batch of {total} S1 structures of ~5k atoms (N(5000, 500^2) clipped to [3000, 7000]), {n_mine} on this rank as one resident multi-model pack"
+        scaling = "strong" if args.structures else "weak"
+    else:
+        wall, dev_ms, n_pairs, acc, n_atoms = measure_resident(aa, _lib, torch, dev, dev_index, cloud(args.workload), prm, args.steps, args.warmup,
+                                                                args.profile_steps, barrier, check)
+        label = f"{args.workload.upper()} synthetic {n_atoms}-atom cloud per GPU (tests/synth.py gen_{args.workload})"
+        scaling = "weak"
+        if not args.no_extras and not args.deterministic and not args.contacts_only:
+            other = "s1" if args.workload == "s2" else "s2"
+            w2, d2, p2, a2, n2 = measure_resident(aa, _lib, torch, dev, dev_index, cloud(other), prm, args.steps, args.warmup, args.profile_steps, barrier, check)
+            w2max, p2all = reduce_job(dist, red_dev, w2, p2)
+            sub[other] = {"workload": f"{other.upper()} synthetic {n2}-atom cloud per GPU", "atoms_per_gpu": n2, "pairs_per_gpu": p2,
+                          "value": p2all * args.steps / w2max, "ms_per_step": w2max / args.steps * 1e3, "roofline": roofline_of(n2, p2, a2, d2)}
+            packs, n_mine = batch(1250 * world)
+            wb, db, pb, ab, nb = measure_resident(aa, _lib, torch, dev, dev_index, packs[0], prm, args.steps, args.warmup, args.profile_steps, barrier, check)
+            wbmax, pball = reduce_job(dist, red_dev, wb, pb)
+            sub["batch5k"] = {"workload": f"BASELINE config 5 shape: {1250 * world} S1 structures of ~5k atoms over {world} GPU(s), longest-first deal, "
+                                          f"{n_mine} on rank 0 as one resident multi-model pack", "structures": 1250 * world, "atoms_per_gpu": nb, "pairs_per_gpu": pb,
+                              "value": pball * args.steps / wbmax, "unit": "classified atom-pairs/s", "ms_per_step": wbmax / args.steps * 1e3,
+                              "us_per_structure": wbmax / args.steps / max(n_mine, 1) * 1e6, "roofline": roofline_of(nb, pb, ab, db)}
+            if rank == 0:  # the host-inclusive path of the same shape: host arrays in, host pair lists out, packed launches (PCIe both ways)
+                import ctypes as C
+
+                sizes = batch5k_sizes(512)
+                soas = batch5k_share(aa, synth, sizes, list(range(512)), pool=16)
+                keep_host = []
+                views = [aa.atoms_from_arrays(s, keep=keep_host) for s in soas]
+                arr = (C.POINTER(_lib.arp_atoms) * len(views))(*[C.pointer(v) for v in views])
+                c2 = aa.Context(dev_index)
+                handles = (C.c_void_p * 1)(c2._h)
+                host = {}
+                for name, only in (("contacts_only", True), ("all_candidates", False)):
+                    hp = aa.default_params(0.1, 6.5, contacts_only=only)
+                    outs = (_lib.arp_pairs * len(views))()
+                    best = None
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        st = _lib.lib.arp_contacts_atomic_batch(handles, 1, arr, len(views), C.byref(hp), outs)
+                        dt = time.perf_counter() - t0
+                        assert st == 0, _lib.lib.arp_last_error()
+                        n_out = sum(int(outs[k].n) for k in range(len(views)))
+                        for k in range(len(views)):
+                            _lib.lib.arp_pairs_free(C.byref(outs[k]))
+                        best = dt if best is None else min(best, dt)
+                    host[name] = {"us_per_structure": best / len(views) * 1e6, "records_out": n_out}
+                sub["batch5k"]["host_path"] = {"structures": len(views), "note": "arp_contacts_atomic_batch: pageable host arrays in, host pair lists out "
+                                               "(PCIe both ways, never the `value`)", **host}
+
+    wall_max, pairs_all = reduce_job(dist, red_dev, wall, n_pairs)  # max over ranks / sum over ranks; no data-path collective
 
     if rank == 0:
         # HBM traffic of the dominant kernel cannot be counted from inside this process; when the run matches the configuration
         # the committed rocprofv3 --pmc passes were taken on, report that measurement (profiles/, with its source), else null.
         traffic = None
-        try:
-            tr = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
-            if tr["workload"] == args.workload and tr["atoms"] == n and not args.deterministic and not args.contacts_only:
-                traffic = {"hbm_bytes_per_launch": tr["hbm_bytes_per_launch"], "kernel": tr["kernel"], "source": tr["source"]}
-        except (OSError, KeyError, ValueError):
-            pass
-        if not acc:  # --profile-steps 0 (external profiler runs): fall back to the whole device-side step
-            acc = {"pipeline": dev_ms / args.steps}
-        dom = max(acc, key=acc.get)
-        alg_bytes = 36.0 * n + 16.0 * n_pairs  # 36 B/atom read once + 16 B per classified pair written
-        dom_ms = acc[dom]
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        pipeline_ms = sum(acc.values())
+        for name in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                tr = json.loads((ROOT / "profiles" / name).read_text())
+                if tr["workload"] == args.workload and tr["atoms"] == n_atoms and not args.deterministic and not args.contacts_only:
+                    traffic = {"hbm_bytes_per_launch": tr["hbm_bytes_per_launch"], "kernel": tr["kernel"], "source": tr["source"]}
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         line = {
             "metric": "classified atom-pairs/s per GPU at 6.5 A cutoff; achieved HBM GB/s vs peak",
             "value": pairs_all * args.steps / wall_max,
             "unit": "classified atom-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload.upper()} synthetic {n}-atom cloud per GPU (tests/synth.py gen_{args.workload}), groups='/', vdw_comp=0.1, dist_cutoff=6.5",
-                "atoms_per_gpu": n, "pairs_per_gpu": n_pairs, "sharding": "one independent structure per rank, no collective",
+                "workload": f"{label}, groups='/', vdw_comp=0.1, dist_cutoff=6.5",
+                "atoms_per_gpu": n_atoms, "pairs_per_gpu": n_pairs, "sharding": "independent structures per rank, no collective",
                 "emitter": ("ordered two-pass" if args.deterministic else "single-pass") + (", contacts only (kind != 0)" if args.contacts_only else ""),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes": alg_bytes, "kernel_ms": dom_ms,
-                "pipeline_ms": pipeline_ms, "pipeline_frac": alg_bytes / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "kernels_ms": acc,
-            },
-            "device_ms_per_step": dev_ms / args.steps,
+            "roofline": roofline_of(n_atoms, n_pairs, acc, dev_ms, traffic),
+            "device_ms_per_step": dev_ms,
         }
+        line.update(sub)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_atoms, args.workload)
         print(json.dumps(line), flush=True)
