@@ -142,6 +142,8 @@ def _load():
         "arp_structure_ints": (vp, [vp, C.c_char_p]),
         "arp_get_contacts": (C.c_int32, [vp, vp, C.c_char_p, C.c_double, C.c_double, C.POINTER(vp)]),
         "arp_get_contacts_mt": (C.c_int32, [vp, vp, C.c_char_p, C.c_double, C.c_double, C.c_int32, C.POINTER(vp)]),
+        "arp_structure_n_residues": (C.c_uint64, [vp]),
+        "arp_structure_fit_planes": (C.c_int32, [vp, vp, _dp, C.POINTER(C.c_uint8)]),
         "arp_set_num_threads": (None, [C.c_int32]),
         "arp_get_num_threads": (C.c_int32, []),
         "arp_table_free": (None, [vp]),

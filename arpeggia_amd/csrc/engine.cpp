@@ -17,6 +17,7 @@
 
 #include "arp_internal.h"
 #include "host_common.h"
+#include "table_dev.h"
 
 namespace arp {
 
@@ -112,6 +113,8 @@ struct arp_context {
     bool have_params = false;
     uint64_t last_capacity = 0;
     bool pending = false;
+    char *scr_dev[2] = {nullptr, nullptr}, *scr_pin[2] = {nullptr, nullptr};  // table path: two grow-only scratch blocks (device / pinned)
+    uint64_t scr_dev_cap[2] = {0, 0}, scr_pin_cap[2] = {0, 0};
     arp_context *peer = nullptr;           // batch path: the second context of this device (own stream + workspace), kept across calls
     uint32_t defer_scale = 1;              // the deferred-probe list is sized defer_scale x the default; grown on overflow
     arp_atoms last_atoms{};                // the enqueued call, kept so that arp_contacts_atomic_result can re-run it after growing a list
@@ -219,6 +222,7 @@ extern "C" void arp_context_destroy(arp_context *ctx) {
     free_workspace(ctx);
     free_staged(ctx);
     if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+    for (int k = 0; k < 2; k++) { if (ctx->scr_dev[k]) (void)hipFree(ctx->scr_dev[k]); if (ctx->scr_pin[k]) (void)hipHostFree(ctx->scr_pin[k]); }
     if (ctx->grp_buf) (void)hipFree(ctx->grp_buf);
     if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
     if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
@@ -876,6 +880,35 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
         }
     return ARP_OK;
 }
+
+// ---- accessors for the table path (table_dev.hip) ---------------------------------------------------------------------------
+namespace arp {
+void *context_stream(arp_context *ctx) { return (void *)ctx->stream; }
+int context_device(arp_context *ctx) { return ctx->device; }
+arp_status context_scratch(arp_context *ctx, int slot, uint64_t dev_bytes, uint64_t pinned_bytes, char **dev, char **pinned) {
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    if (slot < 0 || slot > 1) { set_error("bad scratch slot"); return ARP_ERR_BAD_INPUT; }
+    if (ctx->scr_dev_cap[slot] < dev_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->scr_dev[slot]) (void)hipFree(ctx->scr_dev[slot]);
+        ctx->scr_dev[slot] = nullptr; ctx->scr_dev_cap[slot] = 0;
+        const uint64_t cap = dev_bytes + dev_bytes / 4 + 4096;
+        HIP_TRY(hipMalloc((void **)&ctx->scr_dev[slot], cap));
+        ctx->scr_dev_cap[slot] = cap;
+    }
+    if (ctx->scr_pin_cap[slot] < pinned_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->scr_pin[slot]) (void)hipHostFree(ctx->scr_pin[slot]);
+        ctx->scr_pin[slot] = nullptr; ctx->scr_pin_cap[slot] = 0;
+        const uint64_t cap = pinned_bytes + pinned_bytes / 4 + 4096;
+        HIP_TRY(hipHostMalloc((void **)&ctx->scr_pin[slot], cap, hipHostMallocDefault));
+        ctx->scr_pin_cap[slot] = cap;
+    }
+    *dev = ctx->scr_dev[slot]; *pinned = ctx->scr_pin[slot];
+    return ARP_OK;
+}
+}  // namespace arp
 
 // ---- profiling ---------------------------------------------------------------------------------------------------
 extern "C" arp_status arp_profile_enable(arp_context *ctx, int32_t on) {

@@ -68,6 +68,10 @@ struct arp_structure {
     std::vector<uint32_t> res_h_ptr, res_h_idx, res_cb, res_sg;
     std::string groups_applied;
     bool groups_valid = false;
+    // table.cpp: derived per-structure tables of the table path + the device-resident copy (built on the first arp_get_contacts)
+    void *table_cache = nullptr;
+    void (*table_cache_free)(void *) = nullptr;
+    ~arp_structure() { if (table_cache && table_cache_free) table_cache_free(table_cache); }
 };
 
 namespace arp {

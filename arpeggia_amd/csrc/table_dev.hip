@@ -1,0 +1,487 @@
+// The contact table on the device: SURVEY.md 8f rows f1 (ring / side-chain plane fits, ring-atom and ring-ring rows,
+// complex.rs:301-405, residues.rs:270-298, aromatic.rs:14-64) and f2 (row expansion, the 10-key sort of mod.rs:120-134, the
+// side-chain plane statistics of complex.rs:137-174).  The host (table.cpp) only keeps the bookkeeping: which entities exist and
+// their strings.  Written for gfx950; sorting and scans go through hipCUB (library primitives, not the hot path).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "arp_internal.h"
+#include "host_common.h"
+#include "table_dev.h"
+
+namespace arp {
+
+#define TRY_HIP(expr)                                                                                                     \
+    do {                                                                                                                  \
+        hipError_t e_ = (expr);                                                                                           \
+        if (e_ != hipSuccess) {                                                                                           \
+            set_error("HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__, #expr);       \
+            return (e_ == hipErrorOutOfMemory) ? ARP_ERR_OOM : ARP_ERR_HIP;                                               \
+        }                                                                                                                 \
+    } while (0)
+
+struct PlaneD { double c[3], n[3]; };
+
+// ---- plane fits (residues.rs:270-298): centroid + direction of least variance --------------------------------------
+// The same cyclic Jacobi iteration as the host's former fit (table.cpp fit_plane): nalgebra's svd.u.column(2) is that direction up
+// to sign, and every use folds the angle into [0, 90] degrees.
+__device__ bool fit_plane_dev(const double *x, const double *y, const double *z, const uint32_t *idx, uint32_t lo, uint32_t hi, const uint8_t *bits, uint8_t want,
+                              PlaneD *out) {
+    uint32_t n = 0;
+    double c[3] = {0, 0, 0};
+    for (uint32_t p = lo; p < hi; p++) {
+        const uint32_t a = idx[p];
+        if (!(bits[a] & want)) continue;
+        c[0] += x[a]; c[1] += y[a]; c[2] += z[a];
+        n++;
+    }
+    if (n < 3) return false;  // residues.rs:273
+    for (int k = 0; k < 3; k++) c[k] /= (double)n;
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (uint32_t p = lo; p < hi; p++) {
+        const uint32_t a = idx[p];
+        if (!(bits[a] & want)) continue;
+        const double d[3] = {x[a] - c[0], y[a] - c[1], z[a] - c[2]};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] += d[i] * d[j];
+    }
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 64; sweep++) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-18 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                if (fabs(A[p][q]) <= 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = cs * akp - sn * akq; A[k][q] = sn * akp + cs * akq; }
+                for (int k = 0; k < 3; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = cs * apk - sn * aqk; A[q][k] = sn * apk + cs * aqk; }
+                for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = cs * vkp - sn * vkq; V[k][q] = sn * vkp + cs * vkq; }
+            }
+    }
+    const double e0 = A[0][0], e1 = A[1][1], e2 = A[2][2];
+    double v[3];
+    if (e1 < e0 && e1 <= e2) { v[0] = V[0][1]; v[1] = V[1][1]; v[2] = V[2][1]; }
+    else if (e2 < e0 && e2 < e1) { v[0] = V[0][2]; v[1] = V[1][2]; v[2] = V[2][2]; }
+    else { v[0] = V[0][0]; v[1] = V[1][0]; v[2] = V[2][0]; }
+    const double nn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    for (int k = 0; k < 3; k++) { out->c[k] = c[k]; out->n[k] = v[k] / nn; }
+    return true;
+}
+
+__global__ __launch_bounds__(128) void k_fit_planes(uint32_t n_res, const uint32_t *res_atom_ptr, const uint32_t *res_atom_idx, const uint8_t *bits, const double *x,
+                                                    const double *y, const double *z, PlaneD *ring, PlaneD *sc, uint8_t *valid) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_res) return;
+    const uint32_t lo = res_atom_ptr[r], hi = res_atom_ptr[r + 1];
+    uint8_t any = 0;
+    for (uint32_t p = lo; p < hi; p++) any |= bits[res_atom_idx[p]];
+    uint8_t v = 0;
+    if ((any & 1u) && fit_plane_dev(x, y, z, res_atom_idx, lo, hi, bits, 1u, &ring[r])) v |= 1u;
+    if ((any & 2u) && fit_plane_dev(x, y, z, res_atom_idx, lo, hi, bits, 2u, &sc[r])) v |= 2u;
+    valid[r] = v;
+}
+
+// ---- plane geometry (residues.rs:31-75) ------------------------------------------------------------------------------
+__device__ inline double norm3d(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+__device__ inline double fold_deg(double rad) {  // residues.rs:50-53,70-73
+    if (rad > 1.57079632679489661923) rad = 3.14159265358979323846 - rad;
+    return rad * (180.0 / 3.14159265358979323846264338327950288);
+}
+__device__ inline double point_dist_d(const PlaneD &p, const double q[3]) { const double v[3] = {q[0] - p.c[0], q[1] - p.c[1], q[2] - p.c[2]}; return norm3d(v); }
+__device__ inline double point_angle_d(const PlaneD &p, const double q[3]) {
+    const double v[3] = {q[0] - p.c[0], q[1] - p.c[1], q[2] - p.c[2]};
+    const double dot = p.n[0] * v[0] + p.n[1] * v[1] + p.n[2] * v[2];
+    return fold_deg(acos(dot / (norm3d(p.n) * norm3d(v))));
+}
+__device__ inline double plane_dihedral_d(const PlaneD &a, const PlaneD &b) {
+    const double dot = a.n[0] * b.n[0] + a.n[1] * b.n[1] + a.n[2] * b.n[2];
+    return fold_deg(acos(dot / (norm3d(a.n) * norm3d(b.n))));
+}
+
+// should_compare_residues (complex.rs:94-131) on prepared keys
+struct ResKeyD { int32_t model_serial; uint32_t chain_rank, ord; bool in_l, in_r; };
+__device__ inline bool compare_residues_d(const ResKeyD &a, const ResKeyD &b, bool symmetric) {
+    if (a.model_serial != b.model_serial) return false;
+    if (!((a.in_l && b.in_r) || (b.in_l && a.in_r))) return false;
+    if (a.chain_rank == b.chain_rank) {
+        if (symmetric) return (b.ord > 1u) && (a.ord < b.ord - 1u);
+        const bool neigh = (a.ord == 0u) ? (b.ord == a.ord || b.ord == a.ord + 1u) : (b.ord == a.ord - 1u || b.ord == a.ord || b.ord == a.ord + 1u);
+        return !neigh;
+    }
+    return !(symmetric && a.in_r && b.in_r && a.in_l && b.in_l && a.chain_rank > b.chain_rank);
+}
+
+struct AtomsD {  // what the ring kernels read per atom
+    uint32_t n;
+    const double *x, *y, *z;
+    const uint32_t *attr, *res_ord;
+    const uint16_t *chain_rank, *model;
+    const int32_t *model_serial_of;
+};
+
+// ---- rows ------------------------------------------------------------------------------------------------------------
+// A row = {from entity, to entity, (f32) distance, interaction code}: the layout of arp_pair.  Entity = atom index, or n + ring index.
+__device__ inline void append_row(uint4 *rows, uint32_t *n_rows, uint32_t cap, uint32_t from, uint32_t to, double dist, uint32_t code) {
+    const uint32_t p = atomicAdd(n_rows, 1u);
+    if (p < cap) rows[p] = make_uint4(from, to, __float_as_uint((float)dist), code);  // mod.rs:148: distance narrowed to f32 at table build
+}
+
+// positively ionizable atoms by RESIDUE name (aromatic.rs:18): the only atoms that can make a ring-atom row
+__global__ __launch_bounds__(256) void k_pos_list(AtomsD at, uint32_t *list, uint32_t *n_list) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = a < at.n && (at.attr[a] & ARP_ATTR_POS_RESN);
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(n_list, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (hit) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = a;
+}
+
+// get_ring_atom_contacts (complex.rs:301-352) + find_cation_pi (aromatic.rs:14-29): one block per ring, its threads sweep the
+// (short) list of candidate atoms.  The reference walks an R*-tree of all atoms around every ring centre.
+__global__ __launch_bounds__(256) void k_ring_atom(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, AtomsD at, const uint32_t *pos_list,
+                                                   const uint32_t *n_pos_ptr, double r2, uint4 *rows, uint32_t *n_rows, uint32_t cap) {
+    const uint32_t e = blockIdx.x;
+    if (e >= n_rings) return;
+    const RingEnt ring = rings[e];
+    if (!(ring.flags & 4u)) return;
+    const PlaneD pl = ring_planes[ring.src_res];
+    const ResKeyD rk{ring.model_serial, ring.chain_rank, ring.ord, (ring.flags & 1u) != 0u, (ring.flags & 2u) != 0u};
+    const uint32_t n_pos = *n_pos_ptr;
+    for (uint32_t k = threadIdx.x; k < n_pos; k += blockDim.x) {
+        const uint32_t a = pos_list[k];
+        const int32_t ms = at.model_serial_of[at.model[a]];
+        if (ms != ring.model_serial) continue;
+        const double q[3] = {at.x[a], at.y[a], at.z[a]};
+        const double dx = q[0] - pl.c[0], dy = q[1] - pl.c[1], dz = q[2] - pl.c[2];
+        if (!(dx * dx + dy * dy + dz * dz <= r2)) continue;  // rstar: inclusive (complex.rs:310)
+        const ResKeyD yk{ms, at.chain_rank[a], at.res_ord[a], (at.attr[a] & ARP_ATTR_LIGAND) != 0u, (at.attr[a] & ARP_ATTR_RECEPTOR) != 0u};
+        if (!compare_residues_d(rk, yk, false)) continue;
+        const double dist = point_dist_d(pl, q), theta = point_angle_d(pl, q);
+        if (theta <= 30.0 && dist <= 4.5) append_row(rows, n_rows, cap, at.n + e, a, dist, ARP_CationPi);
+    }
+}
+
+// get_ring_ring_contacts (complex.rs:354-405) + find_pi_pi (aromatic.rs:33-64): ordered ring pairs, k1 in the ligand set, k2 in
+// the receptor set
+__global__ __launch_bounds__(256) void k_ring_ring(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, uint32_t n_atoms, uint4 *rows, uint32_t *n_rows,
+                                                   uint32_t cap) {
+    const uint32_t e1 = blockIdx.x;
+    if (e1 >= n_rings) return;
+    const RingEnt k1 = rings[e1];
+    if (!(k1.flags & 4u) || !(k1.flags & 1u)) return;
+    const PlaneD p1 = ring_planes[k1.src_res];
+    const ResKeyD r1{k1.model_serial, k1.chain_rank, k1.ord, (k1.flags & 1u) != 0u, (k1.flags & 2u) != 0u};
+    for (uint32_t e2 = threadIdx.x; e2 < n_rings; e2 += blockDim.x) {
+        const RingEnt k2 = rings[e2];
+        if (!(k2.flags & 4u) || !(k2.flags & 2u) || k2.model_serial != k1.model_serial) continue;
+        const PlaneD p2 = ring_planes[k2.src_res];
+        const double v[3] = {p1.c[0] - p2.c[0], p1.c[1] - p2.c[1], p1.c[2] - p2.c[2]};
+        const double dist = norm3d(v);
+        if (!(dist <= 6.0)) continue;
+        const ResKeyD r2k{k2.model_serial, k2.chain_rank, k2.ord, (k2.flags & 1u) != 0u, (k2.flags & 2u) != 0u};
+        if (!compare_residues_d(r1, r2k, true)) continue;
+        const double theta = point_angle_d(p1, p2.c), dih = plane_dihedral_d(p1, p2);
+        int code = -1;
+        if (dih <= 30.0) { if (theta <= 30.0) code = ARP_PiSandwichStacking; else if (theta <= 60.0) code = ARP_PiDisplacedStacking; else if (theta <= 90.0) code = ARP_PiParallelInPlaneStacking; }
+        else if (dih <= 60.0) code = ARP_PiTiltedStacking;
+        else if (dih <= 90.0) { if (theta >= 30.0 && theta < 60.0) code = ARP_PiLStacking; else if (dist <= 5.0) code = ARP_PiTStacking; }
+        if (code >= 0) append_row(rows, n_rows, cap, n_atoms + e1, n_atoms + e2, dist, (uint32_t)code);
+    }
+}
+
+// atom-atom rows: one per set bit of the pair's kind word (complex.rs:217-296), in pair order
+__global__ __launch_bounds__(256) void k_count_bits(const arp_pair *pairs, uint32_t n_pairs, uint32_t *bits) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_pairs) bits[p] = (uint32_t)__popc(pairs[p].kind);
+}
+__global__ __launch_bounds__(256) void k_expand_rows(const arp_pair *pairs, uint32_t n_pairs, const uint32_t *first, uint4 *rows, uint32_t cap) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const arp_pair q = pairs[p];
+    uint32_t o = first[p];
+    for (uint32_t b = q.kind; b; b &= b - 1u, ++o)
+        if (o < cap) rows[o] = make_uint4(q.i, q.j, __float_as_uint(q.dist), (uint32_t)(__ffs((int)b) - 1));
+}
+
+// ---- entity ranks and the 10-key sort (mod.rs:120-134) ----------------------------------------------------------------
+// model, from_chain, to_chain, from_resi, from_altloc, from_atomi, to_resi, to_altloc, to_atomi, interaction; ties (the reference's
+// sort is unstable there) by from_insertion, to_insertion, distance.  (resi, altloc, atomi) of an entity collapse into ONE dense rank,
+// computed by sorting the entities once; the rows then sort by five stable radix passes, least significant first.
+__device__ inline uint32_t bias(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+__global__ __launch_bounds__(256) void k_ent_key(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, int pass, const uint32_t *ids,
+                                                 unsigned long long *key) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_ent) return;
+    const uint32_t e = ids ? ids[p] : p;
+    const EntKey k = e < n_atoms ? atom_keys[e] : ring_keys[e - n_atoms];
+    key[p] = pass == 0 ? (unsigned long long)bias(k.atomi) : (((unsigned long long)bias(k.resi) << 32) | k.altloc);
+}
+__global__ __launch_bounds__(256) void k_ent_flags(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint32_t *ids, uint32_t *flag) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_ent) return;
+    auto key_of = [&](uint32_t e) { return e < n_atoms ? atom_keys[e] : ring_keys[e - n_atoms]; };
+    uint32_t f = 0;
+    if (p > 0) {
+        const EntKey a = key_of(ids[p - 1]), b = key_of(ids[p]);
+        f = (a.resi != b.resi || a.altloc != b.altloc || a.atomi != b.atomi) ? 1u : 0u;
+    }
+    flag[p] = f;
+}
+__global__ __launch_bounds__(256) void k_ent_rank(uint32_t n_ent, const uint32_t *ids, const uint32_t *scan, uint32_t *rank) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_ent) rank[ids[p]] = scan[p];
+}
+
+__global__ __launch_bounds__(256) void k_iota(uint32_t n_items, uint32_t *v) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_items) v[p] = p;
+}
+
+struct SortTables {
+    uint8_t name_rank[32];   // interaction code -> rank of its name (the column is a string in the reference)
+};
+__global__ __launch_bounds__(256) void k_row_key(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, int pass, uint32_t n_atoms, const EntKey *atom_keys,
+                                                 const EntKey *ring_keys, const uint32_t *ent_rank, const uint16_t *chain_rank, const uint16_t *model, const uint32_t *model_rank,
+                                                 const RingEnt *rings, SortTables tb, unsigned long long *key) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_rows) return;
+    const uint4 r = rows[perm ? perm[p] : p];
+    auto ins_of = [&](uint32_t e) { return e < n_atoms ? atom_keys[e].icode : ring_keys[e - n_atoms].icode; };
+    auto chain_of = [&](uint32_t e) { return e < n_atoms ? (uint32_t)chain_rank[e] : rings[e - n_atoms].chain_rank; };
+    unsigned long long k = 0;
+    switch (pass) {
+        case 0: k = r.z; break;                                                                           // distance (non-negative f32: bit order == value order)
+        case 1: k = ((unsigned long long)ins_of(r.x) << 32) | ins_of(r.y); break;                         // from_insertion, to_insertion
+        case 2: k = ((unsigned long long)ent_rank[r.y] << 5) | tb.name_rank[r.w & 31u]; break;            // to_resi, to_altloc, to_atomi, interaction
+        case 3: k = ent_rank[r.x]; break;                                                                 // from_resi, from_altloc, from_atomi
+        default: {                                                                                        // model, from_chain, to_chain
+            const uint32_t mr = r.x < n_atoms ? model_rank[model[r.x]] : rings[r.x - n_atoms].model_rank;
+            k = ((unsigned long long)mr << 32) | ((unsigned long long)chain_of(r.x) << 16) | chain_of(r.y);
+        }
+    }
+    key[p] = k;
+}
+
+// final order + collect_sc_stats (complex.rs:137-174): res1 = ligand residue, res2 = receptor residue
+__global__ __launch_bounds__(256) void k_finish_rows(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, uint32_t n_atoms, const uint32_t *atom_sc_src, const RingEnt *rings,
+                                                     const PlaneD *sc_planes, const uint8_t *valid, uint4 *out_rows, float4 *out_sc) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_rows) return;
+    const uint4 r = rows[perm[p]];
+    out_rows[p] = r;
+    const uint32_t s1 = r.x < n_atoms ? atom_sc_src[r.x] : rings[r.x - n_atoms].sc_src, s2 = r.y < n_atoms ? atom_sc_src[r.y] : rings[r.y - n_atoms].sc_src;
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s1 != ARP_NONE && s2 != ARP_NONE && (valid[s1] & 2u) && (valid[s2] & 2u)) {
+        const PlaneD p1 = sc_planes[s1], p2 = sc_planes[s2];
+        sc = make_float4((float)point_dist_d(p1, p2.c), (float)plane_dihedral_d(p1, p2), (float)point_angle_d(p1, p2.c), 1.0f);
+    }
+    out_sc[p] = sc;
+}
+
+// ---- host orchestration ----------------------------------------------------------------------------------------------
+namespace {
+struct Bump {  // carve a scratch block (256-byte aligned pieces)
+    char *base; uint64_t off = 0, cap;
+    template <class T> T *take(uint64_t count) {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += (count * sizeof(T) + 255u) & ~255ull;
+        return p;
+    }
+};
+uint64_t al(uint64_t bytes) { return (bytes + 255u) & ~255ull; }
+}  // namespace
+
+arp_status device_planes(arp_context *ctx, const DevStructure &ds, std::vector<double> *planes, std::vector<uint8_t> *valid) {
+    hipStream_t st = (hipStream_t)context_stream(ctx);
+    const uint64_t nr = ds.n_res;
+    char *dev = nullptr, *pin = nullptr;
+    arp_status s = context_scratch(ctx, 0, 2 * al(nr * sizeof(PlaneD)) + al(nr) + 4096, 0, &dev, &pin);
+    if (s != ARP_OK) return s;
+    Bump b{dev, 0, 0};
+    PlaneD *ring = b.take<PlaneD>(nr), *sc = b.take<PlaneD>(nr);
+    uint8_t *v = b.take<uint8_t>(nr);
+    if (nr) hipLaunchKernelGGL(k_fit_planes, dim3((uint32_t)((nr + 127) / 128)), dim3(128), 0, st, (uint32_t)nr, (const uint32_t *)ds.res_atom_ptr, (const uint32_t *)ds.res_atom_idx,
+                               (const uint8_t *)ds.plane_bits, (const double *)ds.x, (const double *)ds.y, (const double *)ds.z, ring, sc, v);
+    TRY_HIP(hipGetLastError());
+    std::vector<PlaneD> hr(nr), hs(nr);
+    valid->assign(nr, 0);
+    TRY_HIP(hipMemcpyAsync(hr.data(), ring, nr * sizeof(PlaneD), hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipMemcpyAsync(hs.data(), sc, nr * sizeof(PlaneD), hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipMemcpyAsync(valid->data(), v, nr, hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    planes->assign(12 * nr, 0.0);
+    for (uint64_t r = 0; r < nr; r++) {
+        if ((*valid)[r] & 1u) memcpy(&(*planes)[12 * r], &hr[r], sizeof(PlaneD));
+        if ((*valid)[r] & 2u) memcpy(&(*planes)[12 * r + 6], &hs[r], sizeof(PlaneD));
+    }
+    return ARP_OK;
+}
+
+arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vector<RingEnt> &rings, const std::vector<EntKey> &ring_keys, const arp_pair *pairs_dev,
+                        uint64_t n_pairs, double dist_cutoff, TableRowsHost *out) {
+    hipStream_t st = (hipStream_t)context_stream(ctx);
+    const bool timing = getenv("ARP_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "    device_table %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    const uint64_t n = ds.n, nr = ds.n_res, n_rings = rings.size(), n_ent = n + n_rings;
+    if (n_pairs > 0x7FFFFFF0ull / 8 || n_ent > 0x7FFFFFF0ull) { set_error("table too large for 32-bit row indices"); return ARP_ERR_BAD_INPUT; }
+    // rows: <= 5 per pair in principle, but a contacts-only pair carries 1.06 rows on average; sized after the bit count below.
+    // First stage: everything whose size is known up front.
+    size_t cub_scan = 0, cub_sort_ent = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)std::max<uint64_t>(n_pairs, n_ent) + 1);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort_ent, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (int)n_ent, 0, 64);
+    const uint64_t ring_rows_cap = 64 * n_rings + 1024;  // each ring meets a handful of cations / rings; checked below
+    uint64_t need = 2 * al(nr * sizeof(PlaneD)) + al(nr) + al(n_rings * sizeof(RingEnt)) + al(n_rings * sizeof(EntKey)) + al(n * 4) + 4096 + al((n_pairs + 1) * 4) * 2 +
+                    al(std::max(cub_scan, cub_sort_ent)) + al(n_ent * 8) * 2 + al(n_ent * 4) * 4;
+    char *dev = nullptr, *pin = nullptr;
+    arp_status s = context_scratch(ctx, 0, need, al(n_rings * (sizeof(RingEnt) + sizeof(EntKey))) + 4096, &dev, &pin);
+    if (s != ARP_OK) return s;
+    Bump b{dev, 0, need};
+    PlaneD *ring_pl = b.take<PlaneD>(nr), *sc_pl = b.take<PlaneD>(nr);
+    uint8_t *valid = b.take<uint8_t>(nr);
+    RingEnt *d_rings = b.take<RingEnt>(n_rings);
+    EntKey *d_ring_keys = b.take<EntKey>(n_rings);
+    uint32_t *pos_list = b.take<uint32_t>(n);
+    uint32_t *counters = b.take<uint32_t>(64);  // [0] rows, [1] POS atoms
+    uint32_t *bits = b.take<uint32_t>(n_pairs + 1), *first = b.take<uint32_t>(n_pairs + 1);
+    char *cub_tmp = b.take<char>(std::max(cub_scan, cub_sort_ent));
+    unsigned long long *ek0 = b.take<unsigned long long>(n_ent), *ek1 = b.take<unsigned long long>(n_ent);
+    uint32_t *eid0 = b.take<uint32_t>(n_ent), *eid1 = b.take<uint32_t>(n_ent), *eflag = b.take<uint32_t>(n_ent), *ent_rank = b.take<uint32_t>(n_ent);
+
+    if (n_rings) {
+        memcpy(pin, rings.data(), n_rings * sizeof(RingEnt));
+        memcpy(pin + al(n_rings * sizeof(RingEnt)), ring_keys.data(), n_rings * sizeof(EntKey));
+        TRY_HIP(hipMemcpyAsync(d_rings, pin, n_rings * sizeof(RingEnt), hipMemcpyHostToDevice, st));
+        TRY_HIP(hipMemcpyAsync(d_ring_keys, pin + al(n_rings * sizeof(RingEnt)), n_rings * sizeof(EntKey), hipMemcpyHostToDevice, st));
+    }
+    TRY_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(uint32_t), st));
+    auto grid = [](uint64_t items, uint32_t block) { return dim3((uint32_t)std::max<uint64_t>(1, (items + block - 1) / block)); };
+    // f1: plane fits
+    if (nr) hipLaunchKernelGGL(k_fit_planes, grid(nr, 128), dim3(128), 0, st, (uint32_t)nr, (const uint32_t *)ds.res_atom_ptr, (const uint32_t *)ds.res_atom_idx,
+                               (const uint8_t *)ds.plane_bits, (const double *)ds.x, (const double *)ds.y, (const double *)ds.z, ring_pl, sc_pl, valid);
+    // atom-atom rows: bit count -> offsets -> rows (after the total is known)
+    if (n_pairs) {
+        hipLaunchKernelGGL(k_count_bits, grid(n_pairs, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, bits);
+        TRY_HIP(hipMemsetAsync(bits + n_pairs, 0, sizeof(uint32_t), st));
+        size_t tmp = cub_scan;
+        TRY_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, (const uint32_t *)bits, first, (int)n_pairs + 1, st));
+    }
+    // entity ranks: sort the entities by (resi, altloc, atomi), least significant key first; rank = number of key changes before
+    {
+        hipLaunchKernelGGL(k_iota, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, eid0);
+        hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, 0,
+                           (const uint32_t *)nullptr, ek0);
+        size_t tmp = cub_sort_ent;
+        TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tmp, (const unsigned long long *)ek0, ek1, (const uint32_t *)eid0, eid1, (int)n_ent, 0, 32, st));
+        hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, 1,
+                           (const uint32_t *)eid1, ek0);
+        tmp = cub_sort_ent;
+        TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tmp, (const unsigned long long *)ek0, ek1, (const uint32_t *)eid1, eid0, (int)n_ent, 0, 64, st));
+        hipLaunchKernelGGL(k_ent_flags, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys,
+                           (const uint32_t *)eid0, eflag);
+        tmp = cub_scan;
+        TRY_HIP(hipcub::DeviceScan::InclusiveSum(cub_tmp, tmp, (const uint32_t *)eflag, eid1, (int)n_ent, st));
+        hipLaunchKernelGGL(k_ent_rank, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const uint32_t *)eid0, (const uint32_t *)eid1, ent_rank);
+        TRY_HIP(hipGetLastError());
+    }
+    lap("planes+bits+ranks");
+    // how many atom rows?  (one small read-back: the row buffers are sized by it)
+    uint32_t n_atom_rows = 0;
+    if (n_pairs) TRY_HIP(hipMemcpyAsync(&n_atom_rows, first + n_pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    const uint64_t rows_cap = (uint64_t)n_atom_rows + ring_rows_cap;
+    size_t cub_sort_rows = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort_rows, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (int)rows_cap, 0, 64);
+    const uint64_t need2 = al(rows_cap * 16) * 3 + al(rows_cap * 8) * 2 + al(rows_cap * 4) * 2 + al(cub_sort_rows) + 4096;
+    char *dev2 = nullptr, *pin2 = nullptr;  // the row-sized buffers live in a scratch slot of their own: the first one must not move
+    if ((s = context_scratch(ctx, 1, need2, 2 * al(rows_cap * 16) + 4096, &dev2, &pin2)) != ARP_OK) return s;
+    b = Bump{dev2, 0, need2};
+    pin = pin2;
+    lap("scratch");
+    uint4 *rows = b.take<uint4>(rows_cap), *out_rows = b.take<uint4>(rows_cap);
+    float4 *out_sc = b.take<float4>(rows_cap);
+    unsigned long long *rk0 = b.take<unsigned long long>(rows_cap), *rk1 = b.take<unsigned long long>(rows_cap);
+    uint32_t *perm0 = b.take<uint32_t>(rows_cap), *perm1 = b.take<uint32_t>(rows_cap);
+    char *cub_tmp2 = b.take<char>(cub_sort_rows);
+    if (n_pairs) hipLaunchKernelGGL(k_expand_rows, grid(n_pairs, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, (const uint32_t *)first, rows, (uint32_t)rows_cap);
+    TRY_HIP(hipMemcpyAsync(counters, first + (n_pairs ? n_pairs : 0), n_pairs ? sizeof(uint32_t) : 0, hipMemcpyDeviceToDevice, st));
+    // f1: ring rows, appended behind the atom rows
+    AtomsD at{(uint32_t)n, ds.x, ds.y, ds.z, ds.attr, ds.res_ord, ds.chain_rank, ds.model, ds.model_serial_of};
+    if (n_rings) {
+        if (n) hipLaunchKernelGGL(k_pos_list, grid(n, 256), dim3(256), 0, st, at, pos_list, counters + 1);
+        hipLaunchKernelGGL(k_ring_atom, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, at, (const uint32_t *)pos_list,
+                           (const uint32_t *)(counters + 1), dist_cutoff * dist_cutoff, rows, counters, (uint32_t)rows_cap);
+        hipLaunchKernelGGL(k_ring_ring, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (uint32_t)n, rows, counters,
+                           (uint32_t)rows_cap);
+    }
+    uint32_t n_rows = 0;
+    TRY_HIP(hipMemcpyAsync(&n_rows, counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    if (n_rows > rows_cap) { set_error("internal error: more ring rows than reserved (%u > %llu)", n_rows, (unsigned long long)rows_cap); return ARP_ERR_HIP; }
+    lap("rows");
+    // the sort: five stable passes, least significant key first
+    SortTables tb{};
+    {
+        int o[ARP_N_INTERACTIONS];
+        for (int k = 0; k < ARP_N_INTERACTIONS; k++) o[k] = k;
+        std::sort(o, o + ARP_N_INTERACTIONS, [](int a, int c) { return strcmp(arp_interaction_name(a), arp_interaction_name(c)) < 0; });
+        for (int k = 0; k < ARP_N_INTERACTIONS; k++) tb.name_rank[o[k]] = (uint8_t)k;
+    }
+    if (n_rows) {
+        hipLaunchKernelGGL(k_iota, grid(n_rows, 256), dim3(256), 0, st, n_rows, perm0);
+        static const int end_bit[5] = {32, 64, 37, 32, 64};
+        uint32_t *pin_ = perm0, *pout = perm1;
+        for (int pass = 0; pass < 5; pass++) {
+            hipLaunchKernelGGL(k_row_key, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, pass, (uint32_t)n, (const EntKey *)ds.ent_key,
+                               (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint16_t *)ds.chain_rank, (const uint16_t *)ds.model, (const uint32_t *)ds.model_rank,
+                               (const RingEnt *)d_rings, tb, rk0);
+            size_t tmp = cub_sort_rows;
+            TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp2, tmp, (const unsigned long long *)rk0, rk1, (const uint32_t *)pin_, pout, (int)n_rows, 0, end_bit[pass], st));
+            std::swap(pin_, pout);
+        }
+        hipLaunchKernelGGL(k_finish_rows, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, (uint32_t)n, (const uint32_t *)ds.atom_sc_src,
+                           (const RingEnt *)d_rings, (const PlaneD *)sc_pl, (const uint8_t *)valid, out_rows, out_sc);
+        TRY_HIP(hipGetLastError());
+        lap("sort+finish");
+        TRY_HIP(hipMemcpyAsync(pin, out_rows, (size_t)n_rows * 16, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipMemcpyAsync(pin + al((uint64_t)rows_cap * 16), out_sc, (size_t)n_rows * 16, hipMemcpyDeviceToHost, st));
+    }
+    // does the model hold a ring at all?  (complex.rs:50: the reference panics without one)
+    TRY_HIP(hipStreamSynchronize(st));
+    lap("d2h");
+    out->n = n_rows;
+    out->rows.reset(new TableRow[n_rows ? n_rows : 1]);
+    out->sc.reset(new TableSc[n_rows ? n_rows : 1]);
+    const char *src_rows = pin, *src_sc = pin + al((uint64_t)rows_cap * 16);
+    parallel_for((size_t)n_rows * 2, 1u << 16, [&](size_t k0, size_t k1, size_t) {  // two 16-byte arrays, copied in slices by the host workers
+        const size_t a0 = std::min<size_t>(k0, n_rows), a1 = std::min<size_t>(k1, n_rows);
+        if (a1 > a0) memcpy(out->rows.get() + a0, src_rows + a0 * 16, (a1 - a0) * 16);
+        const size_t b0 = std::max<size_t>(k0, n_rows) - n_rows, b1 = std::max<size_t>(k1, n_rows) - n_rows;
+        if (b1 > b0) memcpy(out->sc.get() + b0, src_sc + b0 * 16, (b1 - b0) * 16);
+    });
+    lap("unpack");
+    return ARP_OK;
+}
+
+}  // namespace arp

@@ -207,6 +207,11 @@ arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const char *grou
  * Concurrent calls with different counts do not interfere. */
 arp_status arp_get_contacts_mt(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp,
                                double dist_cutoff, int32_t num_threads, arp_table **out);
+/* The ring / side-chain planes as the device fits them (residues.rs:270-298), per residue of the filtered model in
+ * hierarchy order: planes = n_residues x 12 doubles {ring centre, ring normal, sc centre, sc normal}; valid[r] bit 1 = the residue has a
+ * ring plane, bit 2 = a side-chain plane. */
+uint64_t arp_structure_n_residues(const arp_structure *s);
+arp_status arp_structure_fit_planes(arp_context *ctx, arp_structure *s, double *planes, uint8_t *valid);
 void arp_table_free(arp_table *t);
 uint64_t arp_table_rows(const arp_table *t);
 /* Column by reference name (mod.rs:140-181,209-211): "model" u32; "interaction" i32 code; "distance" f32;

@@ -1,5 +1,7 @@
 """Where the table path spends its time on a large structure (S1: ubiquitin copies on a lattice).  ARP_TIMING=1 prints the stages.
 Usage (GPU box): ARP_TIMING=1 python tests/table_scaling.py [n_atoms]"""
+import ctypes as C
+import os
 import sys
 import time
 from pathlib import Path
@@ -8,21 +10,46 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 import arpeggia_amd as aa  # noqa: E402
 import synth  # noqa: E402
+from arpeggia_amd import _lib  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 rec = synth.gen_s1(n)
 s = aa.Structure.from_records(rec, hierarchy=True)
 ctx = aa.Context(0)
-from arpeggia_amd import _lib  # noqa: E402
+lib = _lib.lib
+
+
+def c_call(threads, host):
+    """arp_get_contacts_mt alone, then the Arrow export: (seconds, seconds, rows)."""
+    if host:
+        os.environ["ARP_TABLE_HOST"] = "1"
+    else:
+        os.environ.pop("ARP_TABLE_HOST", None)
+    t = C.c_void_p()
+    t0 = time.perf_counter()
+    st = lib.arp_get_contacts_mt(ctx._h, s._h, b"/", 0.1, 6.5, threads, C.byref(t))
+    t1 = time.perf_counter()
+    assert st == 0, lib.arp_last_error()
+    arr, sch = _lib.ArrowArray(), _lib.ArrowSchema()
+    lib.arp_set_num_threads(threads)
+    assert lib.arp_table_export_arrow(t, C.byref(arr), C.byref(sch)) == 0
+    t2 = time.perf_counter()
+    rows = int(lib.arp_table_rows(t))
+    C.CFUNCTYPE(None, C.c_void_p)(arr.release)(C.addressof(arr)); C.CFUNCTYPE(None, C.c_void_p)(sch.release)(C.addressof(sch))
+    lib.arp_table_free(t)
+    return t1 - t0, t2 - t1, rows
+
 
 ref = None
-for threads in (1, 4, 16):
-    _lib.lib.arp_set_num_threads(threads)
-    ctx.get_contacts(s)
-    t0 = time.perf_counter()
+for host in (False, True):
+    for threads in (1, 16):
+        c_call(threads, host)  # first call of a structure uploads it / builds its entity tables
+        best = min((c_call(threads, host) for _ in range(3)), key=lambda r: r[0] + r[1])
+        print(f"S1 {s.n_atoms} atoms, {'host assembly (round 1)' if host else 'device table'}, {threads:2d} host thread(s): "
+              f"get_contacts {best[0] * 1e3:7.1f} ms + Arrow export {best[1] * 1e3:6.1f} ms, {best[2]} rows", file=sys.stderr)
+os.environ.pop("ARP_TABLE_HOST", None)
+for threads in (1, 16):
     cols = ctx.get_contacts(s)
-    dt = time.perf_counter() - t0
-    print(f"S1 {s.n_atoms} atoms, {threads} host thread(s): get_contacts {dt * 1e3:.1f} ms, {len(cols['model'])} rows", file=sys.stderr)
     key = tuple(cols[c].tobytes() for c in ("model", "interaction", "distance", "from_atom", "to_atom", "sc_dihedral"))
     assert ref is None or key == ref, "the table must not depend on the thread count"
     ref = key

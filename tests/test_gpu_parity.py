@@ -551,6 +551,45 @@ def _lines_close(got, want):
                 assert abs(float(x) - float(y)) <= tol, (a, b)
 
 
+def test_device_planes_phe4_of_1ubq(ctx):
+    """the ring plane of PHE 4 as fitted ON THE DEVICE against the numbers of the reference's own unit test
+    (residues.rs:355-372; the normal is defined up to sign, nalgebra's SVD returns the negated vector)."""
+    s = aa.load_model(str(synth.DATA / "1ubq.pdb"))
+    nres = int(_lib.lib.arp_structure_n_residues(s._h))
+    planes, valid = np.zeros((nres, 12)), np.zeros(nres, dtype=np.uint8)
+    st = _lib.lib.arp_structure_fit_planes(ctx._h, s._h, planes.ctypes.data_as(C.POINTER(C.c_double)), valid.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert st == 0, _lib.lib.arp_last_error()
+    assert nres == 134 and int((valid & 1).sum()) == 4 and int(((valid & 2) != 0).sum()) == 68  # SURVEY.md 8a: 4 rings, 68 sc planes
+    phe4 = planes[3]  # MET1 GLN2 ILE3 PHE4
+    assert valid[3] & 1
+    assert np.allclose(phe4[0:3], [24.96883333, 34.687, 6.16233333], atol=1e-6)
+    want = np.array([0.53253994, -0.82736044, -0.17853828])
+    assert min(np.abs(phe4[3:6] - want).max(), np.abs(phe4[3:6] + want).max()) < 1e-6
+    # every plane against the oracle's fit (Hestenes SVD there, symmetric Jacobi on the device)
+    orc = ob.Structure.load(str(synth.DATA / "1ubq.pdb"))
+    for pl in orc.planes("ring"):
+        r = int(pl["res_idx"])
+        assert np.allclose(planes[r, 0:3], pl["c"], atol=1e-9)
+        assert min(np.abs(planes[r, 3:6] - pl["n"]).max(), np.abs(planes[r, 3:6] + pl["n"]).max()) < 1e-9
+
+
+def test_device_table_equals_the_host_assembly(ctx, monkeypatch):
+    """The device table (plane fits, ring rows, sort, sc statistics as kernels) against the round-1 host assembly of the same pair
+    list, row for row: 6bft (17 CationPi + 43 pi rows), a stress structure with altlocs and insertion-free ties, two models."""
+    cases = [aa.load_model(str(synth.DATA / "6bft.pdb")), aa.Structure.from_records(synth.gen_stress(n_res=300, seed=5, altlocs=True)),
+             aa.Structure.from_records(synth.gen_stress(n_res=120, seed=9, n_models=2))]
+    for k, s in enumerate(cases):
+        for groups in ("/", "A,B/"):
+            dev_rows = _table_lines(ctx.get_contacts(s, groups, 0.1, 6.5))
+            monkeypatch.setenv("ARP_TABLE_HOST", "1")
+            host_rows = _table_lines(ctx.get_contacts(s, groups, 0.1, 6.5))
+            monkeypatch.delenv("ARP_TABLE_HOST")
+            _lines_close(dev_rows, host_rows)
+            if k == 0 and groups == "/":
+                kinds = [ln.split(",")[1] for ln in dev_rows]
+                assert len(dev_rows) == 7236 and kinds.count("CationPi") == 17 and sum(x.startswith("Pi") for x in kinds) == 43
+
+
 @pytest.mark.parametrize("name,rows", [("1ubq", 532), ("6bft", 7236)])
 def test_table_matches_golden(ctx, name, rows):
     # python/tests/test_arpeggia.py:32-35: 1ubq -> 532 rows; golden CSVs are restatement-derived (tests/golden/make_golden.py)
