@@ -320,6 +320,24 @@ class Context:
             lib.arp_table_free(t)
 
 
+def sap_weight(resn: str, sasa: float) -> float:
+    """hydrophobicity(resn) * clamp(sasa / max side-chain SASA(resn), 0, 1) as src/sap.rs:41-101,198-209 forms it (f32)."""
+    return float(lib.arp_sap_weight(str(resn).encode(), C.c_float(sasa)))
+
+
+def sap_neighbor_sum(ctx: "Context", x, y, z, sidechain, weight, sap_radius: float = 5.0) -> np.ndarray:
+    """The radius sum of the SAP score (src/sap.rs:155-204) on the contact engine's cell list: for every side-chain atom the f32 sum of
+    `weight` over the side-chain atoms within `sap_radius` (itself included).  The per-atom SASA behind the weights is the caller's."""
+    x, y, z = (np.ascontiguousarray(v, dtype="<f8") for v in (x, y, z))
+    m = np.ascontiguousarray(sidechain, dtype=np.uint8)
+    w = np.ascontiguousarray(weight, dtype="<f4")
+    out = np.zeros(len(x), dtype="<f4")
+    dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    _check(lib.arp_sap_neighbor_sum(ctx._h, len(x), x.ctypes.data_as(dp), y.ctypes.data_as(dp), z.ctypes.data_as(dp), m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    w.ctypes.data_as(fp), C.c_float(sap_radius), out.ctypes.data_as(fp)))
+    return out
+
+
 def atomic_contacts_batch(contexts, atoms_list, params: _lib.arp_params | None = None) -> list:
     """Independent structures over one or more device contexts (arp_contacts_atomic_batch): longest-first deal over the
     contexts, small structures packed into shared launches.  Returns one pair array per structure, in input order."""

@@ -1,6 +1,7 @@
 // Host engine: context / workspace management and the C-ABI entry points of the atomic-contact hot path
 // (include/arpeggia_amd.h).  Compiled with hipcc for the HIP runtime API; all device code lives in kernels.hip.
 // There is NO CPU compute path here: without a gfx950 device every compute call returns ARP_ERR_NO_DEVICE.
+#include <cctype>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -878,6 +879,68 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
             set_error("%s", msg[d].c_str());
             return st[d];
         }
+    return ARP_OK;
+}
+
+// ---- SAP neighbour sum (reference src/sap.rs:155-204) ---------------------------------------------------
+extern "C" float arp_sap_weight(const char *resn, float sasa) {
+    // hydrophobicity (Black & Mould minus glycine, sap.rs:41-64) x clamp(sasa / max side-chain SASA (sap.rs:77-101), 0, 1); 0 for residues
+    // without a hydrophobicity value (sap.rs:198-209)
+    static const struct { const char *n; float h, a; } T[] = {
+        {"ALA", 0.616f - 0.501f, 15.395f}, {"ARG", 0.000f - 0.501f, 124.338f}, {"ASN", 0.236f - 0.501f, 90.303f}, {"ASP", 0.028f - 0.501f, 87.601f},
+        {"CYS", 0.680f - 0.501f, 46.456f}, {"GLU", 0.043f - 0.501f, 95.534f}, {"GLN", 0.251f - 0.501f, 99.186f}, {"GLY", 0.000f, 3.229f},
+        {"HIS", 0.165f - 0.501f, 96.532f}, {"ILE", 0.943f - 0.501f, 31.448f}, {"LEU", 0.943f - 0.501f, 30.271f}, {"LYS", 0.283f - 0.501f, 61.962f},
+        {"MET", 0.738f - 0.501f, 65.233f}, {"PHE", 1.000f - 0.501f, 67.945f}, {"PRO", 0.711f - 0.501f, 17.812f}, {"SER", 0.359f - 0.501f, 39.355f},
+        {"THR", 0.450f - 0.501f, 42.648f}, {"TRP", 0.878f - 0.501f, 101.491f}, {"TYR", 0.880f - 0.501f, 94.478f}, {"VAL", 0.825f - 0.501f, 26.702f}};
+    if (!resn) return 0.0f;
+    char up[8] = {0};
+    for (int k = 0; k < 7 && resn[k]; k++) up[k] = (char)toupper((unsigned char)resn[k]);
+    for (const auto &t : T)
+        if (strcmp(t.n, up) == 0) return t.h * std::min(1.0f, std::max(0.0f, sasa / t.a));
+    return 0.0f;
+}
+
+extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const double *x, const double *y, const double *z, const uint8_t *sidechain,
+                                           const float *weight, float sap_radius, float *out) {
+    arp_status s = check_device(ctx);
+    if (s != ARP_OK) return s;
+    if (n && (!x || !y || !z || !sidechain || !weight || !out)) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
+    if (n >= 0xFFFFFFF0ull) { set_error("too many atoms"); return ARP_ERR_BAD_INPUT; }
+    if (!(sap_radius >= 0.0f)) { set_error("bad sap_radius"); return ARP_ERR_BAD_INPUT; }
+    if (n == 0) return ARP_OK;
+    // the grid machinery of the contact search, over the side-chain atoms only: everything else is kept out by the attribute bit that
+    // keeps hydrogens out of the contact grid
+    std::vector<uint32_t> attr(n), zero32(n, 0);
+    std::vector<uint16_t> zero16(n, 0);
+    for (uint64_t i = 0; i < n; i++) attr[i] = sidechain[i] ? (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR) : ARP_ATTR_H;
+    arp_atoms a{};
+    a.n = n; a.x = x; a.y = y; a.z = z; a.attr = attr.data(); a.res_ord = zero32.data(); a.chain_rank = zero16.data(); a.model = zero16.data();
+    a.n_res = 0; a.location = ARP_MEM_HOST;
+    arp_params prm;
+    arp_default_params(&prm);
+    prm.dist_cutoff = (double)sap_radius;
+    if ((s = ensure_workspace(ctx, n)) != ARP_OK) return s;
+    DevAtoms d{};
+    if ((s = stage_inputs(ctx, &a, &d)) != ARP_OK) return s;
+    if ((s = upload_params(ctx, &prm)) != ARP_OK) return s;
+    char *dev = nullptr, *pin = nullptr;
+    if ((s = context_scratch(ctx, 0, 2 * ((n * 4 + 255u) & ~255ull), 2 * ((n * 4 + 255u) & ~255ull), &dev, &pin)) != ARP_OK) return s;
+    float *d_w = (float *)dev, *d_out = (float *)(dev + ((n * 4 + 255u) & ~255ull));
+    memcpy(pin, weight, n * 4);
+    HIP_TRY(hipMemcpyAsync(d_w, pin, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_out, 0, n * 4, ctx->stream));  // atoms outside the side-chain set keep 0
+    const double r2 = (double)(sap_radius * sap_radius);  // sap.rs:183: the product is formed in f32
+    launch_neighbor_sum(d, ctx->ws, (double)sap_radius, r2, d_w, d_out, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    float *h_out = (float *)(pin + ((n * 4 + 255u) & ~255ull));
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws.grid) {  // non-finite coordinates are reported by the grid build through the fix-up kernel only; check here
+        for (uint64_t i = 0; i < n; i++)
+            if (sidechain[i] && !(std::isfinite(x[i]) && std::isfinite(y[i]) && std::isfinite(z[i]))) { set_error("non-finite atom coordinate"); return ARP_ERR_BAD_INPUT; }
+    }
+    memcpy(out, h_out, n * 4);
     return ARP_OK;
 }
 

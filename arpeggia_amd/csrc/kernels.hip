@@ -262,5 +262,6 @@ DEVFN float dist_f32(double s) {
 #include "pairs.inl"
 #include "pairs_lds.inl"
 #include "batch.inl"
+#include "sap.inl"
 
 }  // namespace arp

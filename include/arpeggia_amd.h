@@ -160,6 +160,15 @@ arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs);
 arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms,
                                      int32_t n_structures, const arp_params *params, arp_pairs *outs);
 
+/* ---- SAP neighbour sum: the radius sum of src/sap.rs:155-204 on the same cell list ----
+ * out[i] = sum over the atoms j with sidechain[j] != 0 and |r_j - r_i|^2 <= f64(sap_radius * sap_radius) (inclusive, i itself included) of
+ * weight[j], accumulated in f32, for every atom i with sidechain[i] != 0; 0 for the others.  Host arrays.  The per-atom SASA behind the
+ * weights (src/sasa.rs, rust-sasa) is the caller's: arp_sap_weight gives hydrophobicity(resn) * clamp(sasa / max_sc_asa(resn), 0, 1) as the
+ * reference forms it (sap.rs:41-101,198-209). */
+float arp_sap_weight(const char *resn, float sasa);
+arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const double *x, const double *y, const double *z,
+                                const uint8_t *sidechain, const float *weight, float sap_radius, float *out);
+
 /* Per-kernel device timing of the most recent call (HIP events on the context's stream).  Enable, run, then read.
  * names[k] points to a static string.  Returns the number of kernels recorded (<= cap). */
 arp_status arp_profile_enable(arp_context *ctx, int32_t on);

@@ -1063,6 +1063,46 @@ int orc_get_contacts(const OrcStructure *s, const char *groups, double vdw_comp,
     return ORC_OK;
 }
 
+/* ------------------------------------------------------------------ SAP neighbour sum
+ * src/sap.rs:155-204 of the reference: for every side-chain atom x, the sum over the side-chain atoms y (x itself included) with
+ * |y - x|^2 <= f64(sap_radius * sap_radius) (rstar locate_within_distance: inclusive; the product is formed in f32, sap.rs:183) of
+ * hydrophobicity(resn(y)) * clamp(sasa(y) / max_sc_asa(resn(y)), 0, 1), accumulated in f32 (.sum::<f32>()).  The per-atom SASA itself
+ * (src/sasa.rs, arithmetic in the rust-sasa crate) is out of scope: the caller passes it.  Brute force, index order. */
+static int sap_tables(const char *resn, float *hyd, float *max_asa) {
+    static const struct { const char *n; float h, a; } T[] = {  /* sap.rs:41-64 (Black & Mould minus glycine), sap.rs:77-101 */
+        {"ALA", 0.616f - 0.501f, 15.395f}, {"ARG", 0.000f - 0.501f, 124.338f}, {"ASN", 0.236f - 0.501f, 90.303f}, {"ASP", 0.028f - 0.501f, 87.601f},
+        {"CYS", 0.680f - 0.501f, 46.456f}, {"GLU", 0.043f - 0.501f, 95.534f}, {"GLN", 0.251f - 0.501f, 99.186f}, {"GLY", 0.000f, 3.229f},
+        {"HIS", 0.165f - 0.501f, 96.532f}, {"ILE", 0.943f - 0.501f, 31.448f}, {"LEU", 0.943f - 0.501f, 30.271f}, {"LYS", 0.283f - 0.501f, 61.962f},
+        {"MET", 0.738f - 0.501f, 65.233f}, {"PHE", 1.000f - 0.501f, 67.945f}, {"PRO", 0.711f - 0.501f, 17.812f}, {"SER", 0.359f - 0.501f, 39.355f},
+        {"THR", 0.450f - 0.501f, 42.648f}, {"TRP", 0.878f - 0.501f, 101.491f}, {"TYR", 0.880f - 0.501f, 94.478f}, {"VAL", 0.825f - 0.501f, 26.702f}};
+    char up[8] = {0};
+    for (int k = 0; k < 7 && resn[k]; k++) up[k] = (char)toupper((unsigned char)resn[k]);
+    for (size_t k = 0; k < sizeof T / sizeof T[0]; k++) if (strcmp(T[k].n, up) == 0) { *hyd = T[k].h; *max_asa = T[k].a; return 1; }
+    return 0;
+}
+float orc_sap_weight(const char *resn, float sasa) {  /* sap.rs:198-209: 0 when the residue has no hydrophobicity value */
+    float h, a;
+    if (!sap_tables(resn, &h, &a)) return 0.0f;
+    float q = sasa / a;
+    if (q < 0.0f) q = 0.0f;
+    if (q > 1.0f) q = 1.0f;
+    return h * q;
+}
+void orc_sap_neighbor_sum(int64_t n, const double *x, const double *y, const double *z, const uint8_t *sidechain, const float *weight, float sap_radius,
+                          float *out) {
+    const double r2 = (double)(sap_radius * sap_radius);  /* sap.rs:183 */
+    for (int64_t i = 0; i < n; i++) {
+        float acc = 0.0f;
+        if (sidechain[i])
+            for (int64_t j = 0; j < n; j++) {
+                if (!sidechain[j]) continue;
+                const double dx = x[j] - x[i], dy = y[j] - y[i], dz = z[j] - z[i];
+                if (dx * dx + dy * dy + dz * dz <= r2) acc += weight[j];
+            }
+        out[i] = acc;
+    }
+}
+
 /* ------------------------------------------------------------------ CLI: dump the table as CSV */
 #ifdef ORC_MAIN
 int main(int argc, char **argv) {

@@ -129,6 +129,10 @@ enum { ORC_CLS_DONOR = 1, ORC_CLS_ACCEPTOR = 2, ORC_CLS_WEAK_DONOR = 4, ORC_CLS_
 double orc_angle(const double a[3], const double b[3], const double c[3]);
 double orc_dihedral(const double a[3], const double b[3], const double c[3], const double d[3]);
 int orc_radii(const char *elem, double *cov_single, double *vdw);
+/* SAP neighbour sum (src/sap.rs:155-204), SASA supplied by the caller: see arp_oracle.c */
+float orc_sap_weight(const char *resn, float sasa);
+void orc_sap_neighbor_sum(int64_t n, const double *x, const double *y, const double *z, const uint8_t *sidechain, const float *weight, float sap_radius,
+                          float *out);
 void orc_plane_metrics(const double c1[3], const double n1[3], const double c2[3], const double n2[3], double out[3]);
 
 #ifdef __cplusplus

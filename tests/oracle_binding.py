@@ -170,6 +170,28 @@ class Structure:
         return out
 
 
+def sap_weight(resn: str, sasa: float) -> float:
+    L = lib()
+    L.orc_sap_weight.restype = C.c_float
+    L.orc_sap_weight.argtypes = [C.c_char_p, C.c_float]
+    return float(L.orc_sap_weight(resn.encode(), C.c_float(sasa)))
+
+
+def sap_neighbor_sum(x, y, z, sidechain, weight, sap_radius: float) -> np.ndarray:
+    """src/sap.rs:155-204 restated (brute force, index order, f32 accumulation)."""
+    L = lib()
+    dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    L.orc_sap_neighbor_sum.restype = None
+    L.orc_sap_neighbor_sum.argtypes = [C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8), fp, C.c_float, fp]
+    x, y, z = (np.ascontiguousarray(v, dtype="<f8") for v in (x, y, z))
+    m = np.ascontiguousarray(sidechain, dtype=np.uint8)
+    w = np.ascontiguousarray(weight, dtype="<f4")
+    out = np.zeros(len(x), dtype="<f4")
+    L.orc_sap_neighbor_sum(len(x), x.ctypes.data_as(dp), y.ctypes.data_as(dp), z.ctypes.data_as(dp), m.ctypes.data_as(C.POINTER(C.c_uint8)), w.ctypes.data_as(fp),
+                           C.c_float(sap_radius), out.ctypes.data_as(fp))
+    return out
+
+
 def atom_classes(atoms: np.ndarray) -> np.ndarray:
     atoms = np.ascontiguousarray(atoms, dtype=ATOM_DTYPE)
     base = atoms.ctypes.data

@@ -526,6 +526,40 @@ def test_deferred_list_overflow_grows_and_repeats(monkeypatch):
     monkeypatch.delenv("ARP_DEBUG_DEFER_ENTRIES")
 
 
+# ---------------------------------------------------------------------------------------------- SAP neighbour sum
+def test_sap_neighbor_sum_matches_the_restatement(ctx):
+    """src/sap.rs:155-204: f32 sum of hydrophobicity x relative side-chain SASA over the side-chain atoms within 5 A, self included.
+    The reference accumulates in R*-tree order, the oracle in index order, the device in slot order: f32 sums agree to rounding."""
+    rng = np.random.default_rng(12)
+    for path_or_n in ("6bft", 40000):
+        if path_or_n == "6bft":
+            rec = synth.read_pdb_records(synth.DATA / "6bft.pdb")
+        else:
+            rec = synth.gen_s1(path_or_n)
+        n = len(rec["x"])
+        backbone = np.isin(rec["name"], [b"N", b"CA", b"C", b"O", b"OXT"])
+        side = (~backbone) & (rec["resn"] != b"HOH") & (rec["element"] != b"H")
+        sasa = rng.uniform(0.0, 60.0, n).astype(np.float32)
+        sasa[rng.random(n) < 0.3] = 0.0  # buried atoms
+        names = {nm: nm.decode() for nm in np.unique(rec["resn"])}
+        w = np.array([aa.sap_weight(names[r], float(a)) for r, a in zip(rec["resn"], sasa)], dtype=np.float32)
+        w_orc = np.array([ob.sap_weight(names[r], float(a)) for r, a in zip(rec["resn"], sasa)], dtype=np.float32)
+        assert np.array_equal(w, w_orc) and (w != 0).any() and aa.sap_weight("HOH", 10.0) == 0.0 and aa.sap_weight("GLY", 99.0) == 0.0
+        got = aa.sap_neighbor_sum(ctx, rec["x"], rec["y"], rec["z"], side, w, 5.0)
+        want = ob.sap_neighbor_sum(rec["x"], rec["y"], rec["z"], side, w, 5.0)
+        assert (got[~side] == 0).all() and np.abs(want[side]).max() > 1.0
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, float(np.abs(want).max())), float(np.abs(got - want).max())
+        again = aa.sap_neighbor_sum(ctx, rec["x"], rec["y"], rec["z"], side, w, 5.0)
+        assert np.array_equal(got, again)  # slot order is a function of the input: bit-reproducible
+    # the radius is inclusive and squared in f32 (sap.rs:183)
+    x = np.array([0.0, 5.0, 0.0, float(np.nextafter(np.float64(5.0), 6.0))])
+    y = np.array([0.0, 0.0, 50.0, 50.0])
+    z0 = np.zeros(4)
+    one, all_sc = np.ones(4, dtype=np.float32), np.ones(4, dtype=np.uint8)
+    got = aa.sap_neighbor_sum(ctx, x, y, z0, all_sc, one, 5.0)
+    assert got.tolist() == ob.sap_neighbor_sum(x, y, z0, all_sc, one, 5.0).tolist() == [2.0, 2.0, 1.0, 1.0]
+
+
 # ---------------------------------------------------------------------------------------------- the table (get_contacts)
 def _table_lines(cols):
     out = []
