@@ -237,77 +237,160 @@ static arp_status read_pdb(const char *path, std::vector<Record> *out) {
     return ARP_OK;
 }
 
-// Minimal mmCIF `_atom_site` loop reader (the reference reads mmCIF through pdbtbx as well, utils.rs:53-57).
-static std::vector<std::string> cif_tokens(const std::string &line) {
-    std::vector<std::string> t;
-    size_t i = 0, n = line.size();
-    while (i < n) {
-        while (i < n && isspace((unsigned char)line[i])) i++;
-        if (i >= n) break;
-        if (line[i] == '\'' || line[i] == '"') {
-            char q = line[i++];
-            size_t j = i;
-            while (j < n && !(line[j] == q && (j + 1 == n || isspace((unsigned char)line[j + 1])))) j++;
-            t.push_back(line.substr(i, j - i));
-            i = j + 1;
-        } else {
-            size_t j = i;
-            while (j < n && !isspace((unsigned char)line[j])) j++;
-            t.push_back(line.substr(i, j - i));
-            i = j;
+// mmCIF `_atom_site` reader (the reference reads mmCIF through pdbtbx as well, utils.rs:53-57).  A real CIF 1.1 lexer over the
+// whole file: whitespace-separated tokens, '#' comments, '...' / "..." quoted values (a quote ends only before whitespace),
+// semicolon-delimited multi-line text fields, loop_ rows that wrap over lines, and the non-loop key/value form of a one-row category.
+// Identity columns as pdbtbx 0.12 picks them (recalled from the crate, not verifiable here -- SURVEY.md Appendix B): atom and
+// residue NAMES from label_atom_id / label_comp_id, CHAIN from auth_asym_id and residue NUMBER from auth_seq_id when present (the
+// author numbering PDB files carry), else label_asym_id / label_seq_id; altloc label_alt_id; insertion pdbx_PDB_ins_code; model
+// pdbx_PDB_model_num.
+namespace {
+struct CifTok {
+    enum Kind { End, Value, Tag, Loop, Data, Other } kind = End;
+    const char *b = nullptr, *e = nullptr;
+    bool quoted = false;
+    bool null_value() const { return !quoted && e - b == 1 && (*b == '.' || *b == '?'); }
+};
+struct CifLexer {
+    const char *p, *end;
+    bool bol = true;  // at the beginning of a line
+    CifLexer(const char *b, const char *e) : p(b), end(e) {}
+    static bool ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+    CifTok next() {
+        for (;;) {
+            while (p < end && ws(*p)) { bol = (*p == '\n'); p++; }
+            if (p >= end) return CifTok{};
+            if (*p == '#') { while (p < end && *p != '\n') p++; continue; }
+            break;
         }
+        CifTok t;
+        if (*p == ';' && bol) {  // text field: up to the next line that starts with ';'
+            const char *b = p + 1, *q = b;
+            for (;;) {
+                const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+                if (!nl) { q = end; break; }
+                if (nl + 1 < end && nl[1] == ';') { q = nl; break; }
+                q = nl + 1;
+            }
+            t.kind = CifTok::Value; t.b = b; t.e = q; t.quoted = true;
+            while (t.e > t.b && (t.e[-1] == '\r' || t.e[-1] == '\n')) t.e--;
+            p = q < end ? q + 2 : end;  // past "\n;"
+            bol = false;
+            return t;
+        }
+        bol = false;
+        if (*p == '\'' || *p == '"') {
+            const char quote = *p++;
+            const char *b = p;
+            while (p < end && !(*p == quote && (p + 1 == end || ws(p[1]))) && *p != '\n') p++;
+            t.kind = CifTok::Value; t.b = b; t.e = p; t.quoted = true;
+            if (p < end && *p == quote) p++;
+            return t;
+        }
+        const char *b = p;
+        while (p < end && !ws(*p)) p++;
+        t.b = b; t.e = p;
+        const size_t len = (size_t)(p - b);
+        auto ieq = [&](const char *w, size_t n) { if (len < n) return false; for (size_t k = 0; k < n; k++) if (tolower((unsigned char)b[k]) != w[k]) return false; return true; };
+        if (*b == '_') t.kind = CifTok::Tag;
+        else if (len == 5 && ieq("loop_", 5)) t.kind = CifTok::Loop;
+        else if (ieq("data_", 5)) t.kind = CifTok::Data;
+        else if (ieq("save_", 5) || (len == 7 && ieq("global_", 7)) || (len == 5 && ieq("stop_", 5))) t.kind = CifTok::Other;
+        else t.kind = CifTok::Value;
+        return t;
     }
-    return t;
-}
+};
+}  // namespace
+
 static arp_status read_mmcif(const char *path, std::vector<Record> *out) {
-    std::ifstream f(path);
-    if (!f) { set_error("cannot open '%s'", path); return ARP_ERR_IO; }
-    std::string line;
-    std::vector<std::string> cols;
-    bool in_loop = false, in_atoms = false;
-    std::map<std::string, int> idx;
-    auto get = [&](const std::vector<std::string> &t, const char *primary, const char *fallback) -> std::string {
-        auto it = idx.find(primary);
-        if (it == idx.end() && fallback) it = idx.find(fallback);
-        if (it == idx.end() || it->second >= (int)t.size()) return "";
-        const std::string &v = t[it->second];
-        return (v == "." || v == "?") ? "" : v;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { set_error("cannot open '%s'", path); return ARP_ERR_IO; }
+    std::string buf;
+    {
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, fp)) > 0) buf.append(chunk, got);
+        fclose(fp);
+    }
+    enum Col { GROUP, ID, LABEL_ATOM, AUTH_ATOM, ALT, LABEL_COMP, AUTH_COMP, LABEL_ASYM, AUTH_ASYM, LABEL_SEQ, AUTH_SEQ, INS, X, Y, Z, OCC, ELEM, MODEL, N_COL };
+    static const char *kNames[N_COL] = {"group_pdb", "id", "label_atom_id", "auth_atom_id", "label_alt_id", "label_comp_id", "auth_comp_id", "label_asym_id",
+                                        "auth_asym_id", "label_seq_id", "auth_seq_id", "pdbx_pdb_ins_code", "cartn_x", "cartn_y", "cartn_z", "occupancy",
+                                        "type_symbol", "pdbx_pdb_model_num"};
+    auto col_of = [&](const CifTok &t) -> int {  // _atom_site.<name>, case-insensitive
+        static const char pre[] = "_atom_site.";
+        const size_t len = (size_t)(t.e - t.b);
+        if (len <= 11) return -1;
+        for (size_t k = 0; k < 11; k++) if (tolower((unsigned char)t.b[k]) != pre[k]) return -1;
+        for (int c = 0; c < N_COL; c++) {
+            const size_t n = strlen(kNames[c]);
+            if (len - 11 != n) continue;
+            bool eq = true;
+            for (size_t k = 0; k < n && eq; k++) eq = tolower((unsigned char)t.b[11 + k]) == kNames[c][k];
+            if (eq) return c;
+        }
+        return (int)N_COL;  // an _atom_site column this reader does not use
     };
-    auto upper = [](std::string s) { for (char &c : s) c = (char)toupper((unsigned char)c); return s; };
-    while (std::getline(f, line)) {
-        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-        if (line.empty()) continue;
-        if (line[0] == '#') { in_loop = in_atoms = false; cols.clear(); idx.clear(); continue; }
-        if (line.compare(0, 5, "loop_") == 0) { in_loop = true; in_atoms = false; cols.clear(); idx.clear(); continue; }
-        if (in_loop && line[0] == '_') {
-            std::string name = cif_tokens(line)[0];
-            if (name.compare(0, 11, "_atom_site.") == 0) { in_atoms = true; idx[name.substr(11)] = (int)cols.size(); }
-            cols.push_back(name);
+    auto emit = [&](const CifTok *v) {  // one row: v[c] for the known columns (kind End = absent)
+        auto text = [&](int c, int fallback) -> Field {
+            const CifTok *t = &v[c];
+            if ((t->kind == CifTok::End || t->null_value()) && fallback >= 0) t = &v[fallback];
+            if (t->kind == CifTok::End || t->null_value()) return Field{nullptr, nullptr};
+            return Field{t->b, t->e};
+        };
+        const Field group = text(GROUP, -1);
+        const size_t gl = (size_t)(group.e - group.b);
+        if (!((gl == 4 && memcmp(group.b, "ATOM", 4) == 0) || (gl == 6 && memcmp(group.b, "HETATM", 6) == 0))) return;
+        out->emplace_back();
+        Record &r = out->back();
+        memset(&r, 0, sizeof r);
+        auto fld = [](Field f) { return f.b ? f : Field{"", ""}; };
+        r.serial = (int32_t)field_long(fld(text(ID, -1)));
+        put_field(r.name, sizeof r.name, fld(text(LABEL_ATOM, AUTH_ATOM)), true);
+        put_field(r.altloc, sizeof r.altloc, fld(text(ALT, -1)), false);
+        put_field(r.resn, sizeof r.resn, fld(text(LABEL_COMP, AUTH_COMP)), true);
+        put_field(r.chain, sizeof r.chain, fld(text(AUTH_ASYM, LABEL_ASYM)), false);
+        r.resi = (int32_t)field_long(fld(text(AUTH_SEQ, LABEL_SEQ)));
+        put_field(r.icode, sizeof r.icode, fld(text(INS, -1)), false);
+        r.x = field_double(fld(text(X, -1))); r.y = field_double(fld(text(Y, -1))); r.z = field_double(fld(text(Z, -1)));
+        const Field occ = text(OCC, -1);
+        r.occ = occ.b ? field_double(occ) : 1.0;
+        put_field(r.elem, sizeof r.elem, fld(text(ELEM, -1)), true);
+        const Field mdl = text(MODEL, -1);
+        r.model_serial = mdl.b ? (int32_t)field_long(mdl) : 0;
+    };
+    out->reserve(buf.size() / 90 + 16);
+    CifLexer lex(buf.data(), buf.data() + buf.size());
+    CifTok t = lex.next();
+    CifTok single[N_COL + 1];  // the key/value form (a category with one row)
+    bool have_single = false;
+    while (t.kind != CifTok::End) {
+        if (t.kind == CifTok::Loop) {
+            std::vector<int> cols;
+            bool atoms = false;
+            for (t = lex.next(); t.kind == CifTok::Tag; t = lex.next()) { const int c = col_of(t); cols.push_back(c); atoms = atoms || c >= 0; }
+            if (cols.empty()) continue;
+            CifTok row[N_COL + 1];
+            size_t k = 0;
+            for (; t.kind == CifTok::Value; t = lex.next()) {
+                if (atoms && cols[k] >= 0) row[cols[k]] = t;
+                if (++k == cols.size()) {
+                    if (atoms) { emit(row); for (CifTok &q : row) q = CifTok{}; }
+                    k = 0;
+                }
+            }
             continue;
         }
-        if (!(in_loop && in_atoms)) continue;
-        std::vector<std::string> t = cif_tokens(line);
-        if (t.size() < cols.size()) continue;
-        std::string group = get(t, "group_PDB", nullptr);
-        if (group != "ATOM" && group != "HETATM") continue;
-        Record r{};
-        r.serial = (int32_t)strtol(get(t, "id", nullptr).c_str(), nullptr, 10);
-        put(r.name, sizeof r.name, upper(get(t, "auth_atom_id", "label_atom_id")));
-        put(r.altloc, sizeof r.altloc, get(t, "label_alt_id", nullptr));
-        put(r.resn, sizeof r.resn, upper(get(t, "auth_comp_id", "label_comp_id")));
-        put(r.chain, sizeof r.chain, get(t, "auth_asym_id", "label_asym_id"));
-        r.resi = (int32_t)strtol(get(t, "auth_seq_id", "label_seq_id").c_str(), nullptr, 10);
-        put(r.icode, sizeof r.icode, get(t, "pdbx_PDB_ins_code", nullptr));
-        r.x = strtod(get(t, "Cartn_x", nullptr).c_str(), nullptr);
-        r.y = strtod(get(t, "Cartn_y", nullptr).c_str(), nullptr);
-        r.z = strtod(get(t, "Cartn_z", nullptr).c_str(), nullptr);
-        std::string occ = get(t, "occupancy", nullptr);
-        r.occ = occ.empty() ? 1.0 : strtod(occ.c_str(), nullptr);
-        put(r.elem, sizeof r.elem, upper(get(t, "type_symbol", nullptr)));
-        std::string mdl = get(t, "pdbx_PDB_model_num", nullptr);
-        r.model_serial = mdl.empty() ? 0 : (int32_t)strtol(mdl.c_str(), nullptr, 10);
-        out->push_back(r);
+        if (t.kind == CifTok::Tag) {
+            const int c = col_of(t);
+            CifTok v = lex.next();
+            if (v.kind == CifTok::Value) { if (c >= 0) { single[c] = v; have_single = true; } t = lex.next(); }
+            else t = v;
+            continue;
+        }
+        if (t.kind == CifTok::Data && have_single) { emit(single); for (CifTok &q : single) q = CifTok{}; have_single = false; }
+        t = lex.next();
     }
+    if (have_single) emit(single);
     return ARP_OK;
 }
 

@@ -280,3 +280,54 @@ def write_pdb(rec: dict, path):
         lines.append("ENDMDL")
     lines.append("END")
     Path(path).write_text("\n".join(lines) + "\n")
+
+
+def with_insertion_codes(rec: dict, every: int = 23) -> dict:
+    """Insertion codes the way antibody numbering produces them: every `every`-th residue (in file order, per chain) takes the residue
+    NUMBER of its predecessor and the code 'A' (100, 100A).  Returns a copy."""
+    out = {k: v.copy() for k, v in rec.items()}
+    key = np.char.add(np.char.add(np.char.add(out["model_serial"].astype("U12"), "|"), out["chain"].astype("U8")), np.char.add("|", out["resi"].astype("U12")))
+    _, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    res_of = np.argsort(np.argsort(first))[inv]
+    prev_resi = {}
+    for r in range(1, int(res_of.max()) + 1):
+        if r % every:
+            continue
+        cur, prv = np.flatnonzero(res_of == r), np.flatnonzero(res_of == r - 1)
+        if out["chain"][cur[0]] != out["chain"][prv[0]] or out["model_serial"][cur[0]] != out["model_serial"][prv[0]] or out["icode"][prv[0]] != b"":
+            continue
+        out["resi"][cur] = out["resi"][prv[0]]
+        out["icode"][cur] = b"A"
+    return out
+
+
+def write_mmcif(rec: dict, path, fancy: bool = True):
+    """mmCIF writer for the ingest tests.  `fancy` uses what a minimal line-based reader cannot take: a multi-line semicolon text field,
+    quoted values, rows wrapped over two lines, label_* columns that DIFFER from the author numbering (label_seq_id counts 1, 2, ...;
+    label_asym_id is a letter per chain in order of appearance) next to the auth_* columns PDB files carry, '?' and '.' for absent values."""
+    lines = ["data_synth", "#", "_entry.id synth", "_struct.title", ";A synthetic structure", "with a title over two lines", ";", "#",
+             "loop_", "_entity.id", "_entity.pdbx_description", "1 'first entity'", '2 "second entity, isn\'t it"', "#", "loop_"]
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_seq_id", "pdbx_PDB_ins_code",
+            "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "auth_seq_id", "auth_asym_id", "pdbx_PDB_model_num"]
+    lines += [f"_atom_site.{c}" for c in cols]
+    label_asym, label_seq, last = {}, {}, None
+    for k in range(len(rec["x"])):
+        ch = (int(rec["model_serial"][k]), rec["chain"][k])
+        if ch not in label_asym:
+            label_asym[ch] = "L" + chr(ord("A") + len(label_asym) % 26) if fancy else rec["chain"][k].decode()
+        rkey = (ch, int(rec["resi"][k]), rec["icode"][k])
+        if rkey != last:
+            label_seq[ch] = label_seq.get(ch, 0) + 1
+            last = rkey
+        nm = rec["name"][k].decode()
+        name = f'"{nm}"' if fancy and k % 3 == 0 else (f"'{nm}'" if fancy and k % 3 == 1 else nm)
+        f = ["ATOM", str(int(rec["serial"][k])), rec["element"][k].decode(), name, rec["altloc"][k].decode() or ".", rec["resn"][k].decode(), label_asym[ch],
+             str(label_seq[ch]) if fancy else str(int(rec["resi"][k])), rec["icode"][k].decode() or "?",
+             f"{rec['x'][k]:.3f}", f"{rec['y'][k]:.3f}", f"{rec['z'][k]:.3f}", f"{rec['occupancy'][k]:.2f}", "10.00", str(int(rec["resi"][k])), rec["chain"][k].decode(),
+             str(int(rec["model_serial"][k]) or 1)]
+        if fancy and k % 5 == 4:
+            lines += [" ".join(f[:9]), "   " + " ".join(f[9:])]
+        else:
+            lines.append(" ".join(f))
+    lines.append("#")
+    Path(path).write_text("\n".join(lines) + "\n")

@@ -691,6 +691,27 @@ def test_table_on_stress_structure_matches_oracle_table(ctx, tmp_path):
         _lines_close(_table_lines(cols), want)
 
 
+def test_disk_files_with_altlocs_insertion_codes_and_two_models_end_to_end(ctx, tmp_path):
+    """a file with alternate locations, insertion codes and two MODEL records, read from DISK as PDB and as mmCIF (quoted
+    values, a multi-line text field, wrapped rows, label_* numbering that differs from the author numbering), through contacts() to the table,
+    against the oracle's table of the PDB file."""
+    rec = synth.with_insertion_codes(synth.gen_stress(n_res=160, seed=43, n_models=2, altlocs=True, n_chains=3))
+    pdb, cif = tmp_path / "alt.pdb", tmp_path / "alt.cif"
+    synth.write_pdb(rec, pdb)
+    synth.write_mmcif(rec, cif, fancy=True)
+    orc = ob.Structure.load(pdb)
+    for groups in ("/", "A/B,C"):
+        want = ob.rows_to_csv_lines(orc.get_contacts(groups, 0.1, 6.5))
+        assert len(want) > 500 and any(",A," in ln for ln in want)
+        for path in (pdb, cif):
+            s = aa.load_model(path)
+            _lines_close(_table_lines(ctx.get_contacts(s, groups, 0.1, 6.5)), want)
+    df = aa.contacts(str(cif))
+    assert df.num_rows == len(ob.rows_to_csv_lines(orc.get_contacts("/", 0.1, 6.5)))
+    assert set(df.column("from_insertion").to_pylist()) >= {"", "A"} and set(df.column("from_altloc").to_pylist()) >= {"", "A", "B"}
+    assert set(df.column("model").to_pylist()) == {1, 2}
+
+
 def test_table_multi_model_and_host_threads(ctx, tmp_path):
     """Two models (the plane tables visit all chains of all models under every model serial, complex.rs:447-449) against the
     oracle's table, and the same table for 1 and 8 host threads."""
