@@ -394,9 +394,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
                         float rx[kReadAhead], ry[kReadAhead], rz[kReadAhead], rw[kReadAhead];
 #pragma unroll
                         for (uint32_t u = 0; u < kReadAhead; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; rw[u] = r.w; }
+                        // |n|^2 - 2 n.h against thr = r2m - |h|^2: 5 VALU per test.  The three FMAs of ONE test are a dependent chain (~2 ns per
+                        // link on a SIMD, tests/microbench/valu_rate.hip); issued test-major they serialise, so the loop runs link-major over the
+                        // kReadAhead tests in flight: neighbouring instructions are independent.
+                        float acc[kReadAhead];
 #pragma unroll
-                        for (uint32_t u = 0; u < kReadAhead; ++u)  // |n|^2 - 2 n.h against thr = r2m - |h|^2: 5 VALU per test
-                            push_pass(mask, __fmaf_rn(rz[u], hm2.z, __fmaf_rn(ry[u], hm2.y, __fmaf_rn(rx[u], hm2.x, rw[u]))), thr);
+                        for (uint32_t u = 0; u < kReadAhead; ++u) acc[u] = __fmaf_rn(rx[u], hm2.x, rw[u]);
+#pragma unroll
+                        for (uint32_t u = 0; u < kReadAhead; ++u) acc[u] = __fmaf_rn(ry[u], hm2.y, acc[u]);
+#pragma unroll
+                        for (uint32_t u = 0; u < kReadAhead; ++u) acc[u] = __fmaf_rn(rz[u], hm2.z, acc[u]);
+#pragma unroll
+                        for (uint32_t u = 0; u < kReadAhead; ++u) push_pass(mask, acc[u], thr);
                     }
 #if defined(ARP_PAD)   // timing probe: ARP_PAD extra VALU instructions per block (is the kernel VALU-issue bound?)
                     {
@@ -683,6 +692,7 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 }
 
 void launch_emit_x(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
+void launch_emit_b(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only) {
     if (in.n >= kBigSlots) {  // beyond the 32-bit record offsets of the single-pass kernel: count + ordered fill with inline probes
@@ -695,6 +705,8 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     // against 240 us for this kernel), so the gather kernel stays the default.
     static const bool use_lds_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'l'; }();
     if (use_lds_kernel) { launch_emit_x(in, ws, out, capacity, st, prof); return; }
+    static const bool use_blk_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'b'; }();
+    if (use_blk_kernel) { launch_emit_b(in, ws, out, capacity, st, prof); return; }
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1600)
         const char *e = getenv("ARP_EMIT_BLOCKS");

@@ -63,21 +63,10 @@ DEVFN unsigned long long compact_round_x(uint32_t &mask, uint32_t tag, uint32_t 
     return m;
 }
 
-// Phase 2 on up to 64 survivors, both operands out of LDS.  slot0 / cs: global slot of home lane 0 / of chunk record 0 (for
-// the deferred list, whose entries are global slot pairs).
-DEVFN void exact_batch_x(const LdsParams &prm, WaveLdsX &w, BlockLds &bl, uint32_t e, bool active, uint32_t slot0, uint32_t cs,
-                         const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t have_res) {
-    const uint32_t hl = e >> 16, bi = e & 0xFFFFu;
-    Fat a, b;
-    {   // (inactive lanes of a partial batch read record 0 of both tables: in bounds, ignored)
-        const u32x4 axy = w.hxy[hl], bxy = w.xy[bi];
-        const u32x4 azm = w.hzm[hl], bzm = w.zm[bi];
-        const u32x2 aco = w.hco[hl], bco = w.co[bi];
-        a.x = __hiloint2double((int)axy.y, (int)axy.x); a.y = __hiloint2double((int)axy.w, (int)axy.z); a.z = __hiloint2double((int)azm.y, (int)azm.x);
-        a.pw = azm.z; a.res_ord = azm.w; a.crm = aco.x; a.orig = aco.y;
-        b.x = __hiloint2double((int)bxy.y, (int)bxy.x); b.y = __hiloint2double((int)bxy.w, (int)bxy.z); b.z = __hiloint2double((int)bzm.y, (int)bzm.x);
-        b.pw = bzm.z; b.res_ord = bzm.w; b.crm = bco.x; b.orig = bco.y;
-    }
+// The part of phase 2 behind the operand fetch: exact f64 decision, pair filter, classification, compacted coalesced store.
+// slot_a / slot_b: global slots of the two records (for the deferred list, whose entries are global slot pairs).
+DEVFN void exact_tail(const LdsParams &prm, BlockLds &bl, const Fat &a, const Fat &b, bool active, uint32_t slot_a, uint32_t slot_b, const EmitTarget &tg,
+                      unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t have_res) {
     const double s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
     const int o = (wflags & kWaveAllBoth) ? orient_all_both(a, b) : orient(a, b);
     bool valid = active & (s <= prm.r2) & (o != 0);  // rstar: inclusive
@@ -97,7 +86,7 @@ DEVFN void exact_batch_x(const LdsParams &prm, WaveLdsX &w, BlockLds &bl, uint32
             if (defer) {
                 const uint32_t dr = mbcnt(dm);
                 const unsigned long long p = dr < ds.n0 ? ds.pos0 + dr : ds.pos1 + (dr - ds.n0);
-                if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(slot0 + hl, cs + bi); else atomicOr(&result[1], 8ull);
+                if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(slot_a, slot_b); else atomicOr(&result[1], 8ull);
             }
             valid = valid && !defer;
         }
@@ -115,6 +104,24 @@ DEVFN void exact_batch_x(const LdsParams &prm, WaveLdsX &w, BlockLds &bl, uint32
             if (d) *d = r;
         }
     }
+}
+
+// Phase 2 on up to 64 survivors, both operands out of LDS.  slot0 / cs: global slot of home lane 0 / of chunk record 0 (for
+// the deferred list, whose entries are global slot pairs).
+DEVFN void exact_batch_x(const LdsParams &prm, WaveLdsX &w, BlockLds &bl, uint32_t e, bool active, uint32_t slot0, uint32_t cs,
+                         const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t have_res) {
+    const uint32_t hl = e >> 16, bi = e & 0xFFFFu;
+    Fat a, b;
+    {   // (inactive lanes of a partial batch read record 0 of both tables: in bounds, ignored)
+        const u32x4 axy = w.hxy[hl], bxy = w.xy[bi];
+        const u32x4 azm = w.hzm[hl], bzm = w.zm[bi];
+        const u32x2 aco = w.hco[hl], bco = w.co[bi];
+        a.x = __hiloint2double((int)axy.y, (int)axy.x); a.y = __hiloint2double((int)axy.w, (int)axy.z); a.z = __hiloint2double((int)azm.y, (int)azm.x);
+        a.pw = azm.z; a.res_ord = azm.w; a.crm = aco.x; a.orig = aco.y;
+        b.x = __hiloint2double((int)bxy.y, (int)bxy.x); b.y = __hiloint2double((int)bxy.w, (int)bxy.z); b.z = __hiloint2double((int)bzm.y, (int)bzm.x);
+        b.pw = bzm.z; b.res_ord = bzm.w; b.crm = bco.x; b.orig = bco.y;
+    }
+    exact_tail(prm, bl, a, b, active, slot0 + hl, cs + bi, tg, result, lane, wflags, have_res);
 }
 
 // Everything a wave fetches from global memory is requested one step ahead of its use: the records of chunk i+1 while chunk i is
@@ -295,9 +302,18 @@ __global__ __launch_bounds__(kXWaves * 64, 3) void k_pairs_x(DevAtoms in, const 
                     float rx[kXReadAhead], ry[kXReadAhead], rz[kXReadAhead], rw[kXReadAhead];
 #pragma unroll
                     for (uint32_t u = 0; u < kXReadAhead; ++u) { const f32x4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; rw[u] = r.w; }
+                    // |n|^2 - 2 n.h against thr = r2m - |h|^2: 5 VALU per test.  The three FMAs of ONE test are a dependent chain (~2 ns per
+                    // link on a SIMD, tests/microbench/valu_rate.hip); issued test-major they serialise, so the loop runs link-major over the
+                    // kXReadAhead tests in flight: neighbouring instructions are independent.
+                    float acc[kXReadAhead];
 #pragma unroll
-                    for (uint32_t u = 0; u < kXReadAhead; ++u)  // |n|^2 - 2 n.h against thr = r2m - |h|^2: 5 VALU per test
-                        push_pass(mask, __fmaf_rn(rz[u], hm2.z, __fmaf_rn(ry[u], hm2.y, __fmaf_rn(rx[u], hm2.x, rw[u]))), thr);
+                    for (uint32_t u = 0; u < kXReadAhead; ++u) acc[u] = __fmaf_rn(rx[u], hm2.x, rw[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < kXReadAhead; ++u) acc[u] = __fmaf_rn(ry[u], hm2.y, acc[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < kXReadAhead; ++u) acc[u] = __fmaf_rn(rz[u], hm2.z, acc[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < kXReadAhead; ++u) push_pass(mask, acc[u], thr);
                 }
                 const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
                 if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);

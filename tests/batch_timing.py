@@ -14,6 +14,7 @@ import synth  # noqa: E402
 from arpeggia_amd import _lib  # noqa: E402
 
 n_structs = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+trace_only = len(sys.argv) > 2  # under rocprofv3: only the packed contacts-only batch, once warmed up
 rng = np.random.default_rng(5)
 sizes = np.clip(np.rint(rng.normal(5000.0, 500.0, 32)), 3000, 7000).astype(int)
 base = [aa.Structure.from_records(synth.gen_s1(int(n), seed=900 + k), hierarchy=True) for k, n in enumerate(sizes)]
@@ -24,9 +25,9 @@ atoms = sum(s.n_atoms for s in structs)
 canon = lambda a: a[np.lexsort((a["j"], a["i"]))]
 arr = (C.POINTER(_lib.arp_atoms) * n_structs)(*[C.pointer(v) for v in views])
 handles = (C.c_void_p * 1)(ctx._h)
-for only in (True, False):
+for only in ((True,) if trace_only else (True, False)):
     prm = aa.default_params(contacts_only=only)
-    n_single = min(n_structs, 256)
+    n_single = min(n_structs, 8 if trace_only else 256)
     ctx.atomic_contacts(views[0], prm)
     t0 = time.perf_counter()
     singles = [ctx.atomic_contacts(v, prm) for v in views[:n_single]]

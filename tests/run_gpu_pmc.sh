@@ -8,7 +8,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > $OUT/pass$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --profile-steps 0 > $OUT/pass$i.log 2>&1
   rc=$?; echo "pass $i [$line] rc=$rc"
   if [ $rc -ge 124 ]; then exit $rc; fi
 done <<'PASSES'

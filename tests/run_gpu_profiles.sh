@@ -1,0 +1,18 @@
+#!/bin/bash
+# Everything that goes under profiles/ for a round, in one gpurun call.  Usage: bash tests/run_gpu_profiles.sh TAG
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -3 $OUT/bench.err; exit 1; }
+echo "bench done"
+timeout -k 10 300 python tests/batch_timing.py 2048 > $OUT/batch_5k.txt 2>&1; tail -6 $OUT/batch_5k.txt
+ARP_TIMING=1 timeout -k 10 300 python tests/table_scaling.py 1000000 > $OUT/table_1e6.txt 2>&1; grep "S1 " $OUT/table_1e6.txt
+timeout -k 10 200 python tests/e2e_timing.py > $OUT/e2e.txt 2>&1; tail -12 $OUT/e2e.txt
+timeout -k 10 200 python tests/small_timing.py > $OUT/small.txt 2>&1; tail -6 $OUT/small.txt
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --profile-steps 0 > $OUT/stats.log 2>&1
+find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -12
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tests/batch_timing.py 2048 trace > $OUT/trace.log 2>&1
+python3 $GRAFT_REPO_ROOT/tests/trace_overlap.py $OUT/trace > $OUT/batch_overlap.txt 2>&1; cat $OUT/batch_overlap.txt
+rm -rf $OUT/trace/*/*kernel_trace.csv $OUT/trace/*/*memory_copy_trace.csv 2>/dev/null
+cd $GRAFT_REPO_ROOT && bash tests/run_gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary.txt; grep -A8 "k_pairs<2, false>" $OUT/pmc_summary.txt | head -10
