@@ -57,6 +57,18 @@ DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, 
 // Bounding box in two launches: per-block partial results with plain stores, then one block reduces them and sizes the grid.
 // (A single launch with an arrival ticket was measured 2-3x slower: the per-block device-scope atomics / write-through
 // stores cost more than the extra launch.)  partials: [kBoundsBlocks][8] doubles = {min xyz, max xyz, models, bad}.
+// Loads of the caller's arrays, each read once per pass.  ARP_NT_LOAD (diagnostic builds): non-temporal.
+#ifndef ARP_NT_LOAD
+#define ARP_NT_LOAD 0
+#endif
+#ifndef ARP_NT_PLACE
+#define ARP_NT_PLACE 0
+#endif
+#if ARP_NT_LOAD
+#define ARP_LD(p) __builtin_nontemporal_load(&(p))
+#else
+#define ARP_LD(p) (p)
+#endif
 struct BoxAcc {
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t models = 0, bad = 0;
@@ -98,8 +110,8 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = min(i0 + (uint32_t)u * stride, last);
-            at[u] = in.attr[i]; md[u] = (uint32_t)in.model[i];
-            p[u][0] = in.x[i]; p[u][1] = in.y[i]; p[u][2] = in.z[i];
+            at[u] = ARP_LD(in.attr[i]); md[u] = (uint32_t)ARP_LD(in.model[i]);
+            p[u][0] = ARP_LD(in.x[i]); p[u][1] = ARP_LD(in.y[i]); p[u][2] = ARP_LD(in.z[i]);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -225,33 +237,54 @@ DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uin
     return (layer * g.ny + cy) * g.nx + cx;
 }
 
-// Cell of every atom and its arrival rank inside the cell.  Atoms that are consecutive in the input and fall into the same
-// cell (the common case: a residue, a lattice column) share ONE returning atomic issued by the head of the run; a
-// scattered-address atomic wave-instruction costs about a microsecond, so fewer of them is what matters here.
-__global__ __launch_bounds__(256) void k_cellid(DevAtoms in, const GridParams *gp, uint32_t *cell_of_atom, uint32_t *rank_of_atom,
-                                                uint32_t *cell_count) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t c = ARP_NONE;
-    if (i < in.n && !(in.attr[i] & ARP_ATTR_H)) {
-        GridParams g = *gp;
-        c = cell_index(g, in.x[i], in.y[i], in.z[i], in.model[i]);
+// Cell of every atom and its arrival rank inside the cell.  A block takes 1024 consecutive atoms and merges those that fall into
+// the same cell in an LDS hash table first (atoms that are close in the input are close in space: a residue, a chain segment,
+// a lattice column), so each distinct cell of the block costs ONE returning device atomic -- scattered device atomics are what
+// bounds this kernel (about 14 per ns over the whole chip).  rank = the cell's base for this block + the arrival rank in the block.
+constexpr uint32_t kCidThreads = 256, kCidPer = 4, kCidTable = 2048;
+__global__ __launch_bounds__(kCidThreads) void k_cellid(DevAtoms in, const GridParams *gp, uint32_t *cell_of_atom, uint32_t *rank_of_atom,
+                                                        uint32_t *cell_count) {
+    __shared__ uint32_t t_key[kCidTable], t_cnt[kCidTable];
+    for (uint32_t k = threadIdx.x; k < kCidTable; k += kCidThreads) { t_key[k] = ARP_NONE; t_cnt[k] = 0u; }
+    const GridParams g = *gp;
+    const uint32_t i0 = blockIdx.x * (kCidThreads * kCidPer) + threadIdx.x, last = in.n - 1u;  // (never launched with n == 0)
+    double p[kCidPer][3];
+    uint32_t at[kCidPer], md[kCidPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kCidPer; u++) {  // unconditional loads from a clamped index: all of them in flight together
+        const uint32_t i = min(i0 + u * kCidThreads, last);
+        at[u] = ARP_LD(in.attr[i]); md[u] = (uint32_t)ARP_LD(in.model[i]);
+        p[u][0] = ARP_LD(in.x[i]); p[u][1] = ARP_LD(in.y[i]); p[u][2] = ARP_LD(in.z[i]);
     }
-    const uint32_t prev = (uint32_t)__shfl_up((int)c, 1);
-    const bool head = (c != ARP_NONE) && (lane == 0 || prev != c);
-    const unsigned long long heads = __ballot(head), live = __ballot(c != ARP_NONE);
-    uint32_t r = 0;
-    if (c != ARP_NONE) {
-        // run = [start, end): start = last head at or below this lane, end = next head (or next dead lane) above it
-        const unsigned long long below = heads & ((2ull << lane) - 1ull);
-        const uint32_t start = 63u - (uint32_t)__clzll((long long)below);
-        const unsigned long long stop = (heads | ~live) >> start >> 1;  // boundaries above the run head
-        const uint32_t len = stop ? (uint32_t)__ffsll((long long)stop) : 64u - start;
-        uint32_t base = 0;
-        if (head) base = atomicAdd(&cell_count[c], len);
-        r = (uint32_t)__shfl((int)base, (int)start) + (lane - start);
+    __syncthreads();
+    uint32_t c[kCidPer], slot[kCidPer], r[kCidPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kCidPer; u++) {
+        const bool use = (i0 + u * kCidThreads < in.n) & !(at[u] & ARP_ATTR_H);
+        c[u] = use ? cell_index(g, p[u][0], p[u][1], p[u][2], md[u]) : ARP_NONE;
+        slot[u] = 0u; r[u] = 0u;
+        if (use) {
+            uint32_t h = (c[u] * 0x9E3779B1u) >> 21;  // 11 bits
+            for (;;) {  // linear probing; at most 1024 keys in 2048 entries
+                const uint32_t old = atomicCAS(&t_key[h], ARP_NONE, c[u]);
+                if (old == ARP_NONE || old == c[u]) break;
+                h = (h + 1u) & (kCidTable - 1u);
+            }
+            slot[u] = h;
+            r[u] = atomicAdd(&t_cnt[h], 1u);
+        }
     }
-    if (i < in.n) { cell_of_atom[i] = c; rank_of_atom[i] = r; }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kCidTable; k += kCidThreads) {
+        const uint32_t key = t_key[k];
+        if (key != ARP_NONE) t_cnt[k] = atomicAdd(&cell_count[key], t_cnt[k]);  // count -> base of this block's atoms in the cell
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kCidPer; u++) {
+        const uint32_t i = i0 + u * kCidThreads;
+        if (i < in.n) { cell_of_atom[i] = c[u]; rank_of_atom[i] = c[u] != ARP_NONE ? t_cnt[slot[u]] + r[u] : 0u; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- scan
@@ -356,11 +389,17 @@ DEVFN uint32_t make_pair_word(uint32_t attr, bool res_has_h) {
 }
 
 DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so, uint32_t i, uint32_t c, uint32_t d) {
-    const double x = in.x[i], y = in.y[i], z = in.z[i];
+    const double x = ARP_LD(in.x[i]), y = ARP_LD(in.y[i]), z = ARP_LD(in.z[i]);
     double mx = gp->mx, my = gp->my, mz = gp->mz;
     if (gp->model_org) { const double *o = gp->model_org + 6u * (uint32_t)in.model[i] + 3u; mx = o[0]; my = o[1]; mz = o[2]; }
     const float fx = (float)(x - mx), fy = (float)(y - my), fz = (float)(z - mz);
-    so.rec[d] = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
+    const float4 rv = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
+#if ARP_NT_PLACE   // diagnostic: the sorted copies streamed past the L2 as well
+    { typedef float pl_f32x4 __attribute__((ext_vector_type(4))); const pl_f32x4 v = {rv.x, rv.y, rv.z, rv.w};
+      __builtin_nontemporal_store(v, reinterpret_cast<pl_f32x4 *>(so.rec + d)); }
+#else
+    so.rec[d] = rv;
+#endif
     // "the residue carries hydrogens" as a bit of the record: the hot kernel never touches the hydrogen tables, the deferred
     // pass resolves residue -> hydrogens itself (hbond.rs:38-42)
     bool has_h = false;
@@ -368,13 +407,20 @@ DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so
         const uint32_t r = in.res_id[i];
         has_h = in.res_h_ptr[r] < in.res_h_ptr[r + 1];
     }
-    const uint32_t attr = in.attr[i] & ~kAttrResHasH;
+    const uint32_t attr = ARP_LD(in.attr[i]) & ~kAttrResHasH;
     Fat f;
     f.x = x; f.y = y; f.z = z;
-    f.pw = make_pair_word(attr, has_h); f.res_ord = in.res_ord[i];
-    f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i; f.cell = c;
+    f.pw = make_pair_word(attr, has_h); f.res_ord = ARP_LD(in.res_ord[i]);
+    f.crm = (uint32_t)ARP_LD(in.chain_rank[i]) | ((uint32_t)ARP_LD(in.model[i]) << 16); f.orig = i; f.cell = c;
     f.attr = attr | (has_h ? kAttrResHasH : 0u);
+#if ARP_NT_PLACE
+    { typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
+      pl_u32x4 q[3]; __builtin_memcpy(q, &f, 48);
+      pl_u32x4 *dst = reinterpret_cast<pl_u32x4 *>(so.fat + d);
+      __builtin_nontemporal_store(q[0], dst); __builtin_nontemporal_store(q[1], dst + 1); __builtin_nontemporal_store(q[2], dst + 2); }
+#else
     so.fat[d] = f;
+#endif
 }
 
 // Emit mode: slot = cell_start + arrival rank.  Reads are coalesced (input order), each atom writes its 72 bytes once.

@@ -90,6 +90,21 @@ struct EmitTarget {  // positions >= capacity spill into the engine's scratch so
     arp_pair *scratch; unsigned long long scratch_cap;
     uint2 *defer_list; unsigned long long defer_cap;  // candidates whose classification needs a hydrogen / disulfide probe
 };
+// Record stores are non-temporal: streamed past the L2 instead of left dirty in it.  The list is write-once and 16 B x P (460 MB on
+// the headline input); kept in the L2 it evicts the sorted records the gathers want and its write-back lands on whatever runs next
+// (measured: emit 244 -> 222 us, the following grid build 113 -> 88 us).  ARP_NT_STORE=0 builds the plain stores for comparison.
+#ifndef ARP_NT_STORE
+#define ARP_NT_STORE 1
+#endif
+typedef uint32_t rec_u32x4 __attribute__((ext_vector_type(4)));
+DEVFN void store_record(uint4 *p, const uint4 &r) {
+#if ARP_NT_STORE
+    const rec_u32x4 v = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<rec_u32x4 *>(p));
+#else
+    *p = r;
+#endif
+}
 DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned long long *result) {
     if (pos < tg.capacity) return reinterpret_cast<uint4 *>(tg.out) + pos;
     const unsigned long long q = pos - tg.capacity;
@@ -255,14 +270,14 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
 #if defined(ARP_ABLATE) && ARP_ABLATE == 11
                     if (valid && r.w == 0xDEADBEEFu) run[rank] = r;
 #else
-                    if (valid) run[rank] = r;
+                    if (valid) store_record(&run[rank], r);
 #endif
                 } else if (valid) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
                     uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
 #if defined(ARP_ABLATE) && ARP_ABLATE == 11   // timing ablation: allocation but no store
                     if (d && r.w == 0xDEADBEEFu) *d = r;
 #else
-                    if (d) *d = r;
+                    if (d) store_record(d, r);
 #endif
                 }
             }
@@ -637,7 +652,7 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
                        ws.task_ctr, in.per_model ? (const uint32_t *)ws.model_box : (const uint32_t *)nullptr, ws.model_org);
     P1();
     P0("grid_count");
-    if (n) hipLaunchKernelGGL(k_cellid, dim3(nb), dim3(256), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
+    if (n) hipLaunchKernelGGL(k_cellid, dim3((n + kCidThreads * kCidPer - 1u) / (kCidThreads * kCidPer)), dim3(kCidThreads), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
     P1();
     P0("grid_scan");
     launch_scan<uint32_t, true, false>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, ws.tickets + 1, ws, 0ull, false, st);

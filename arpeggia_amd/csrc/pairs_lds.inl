@@ -98,10 +98,10 @@ DEVFN void exact_tail(const LdsParams &prm, BlockLds &bl, const Fat &a, const Fa
         const uint32_t rank = mbcnt(vm);
         if (sl.n0 == n && sl.pos0 + n <= tg.capacity) {  // one run inside the caller's buffer: scalar base + 32-bit lane offset
             uint4 *run = reinterpret_cast<uint4 *>(tg.out) + sl.pos0;
-            if (valid) run[rank] = r;
+            if (valid) store_record(&run[rank], r);
         } else if (valid) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
             uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
-            if (d) *d = r;
+            if (d) store_record(d, r);
         }
     }
 }

@@ -265,6 +265,15 @@ def main():
 
     def cloud(workload):  # one structure per rank, its own seed: independent structures shard with no exchange
         rec = getattr(synth, f"gen_{workload}")(args.atoms, seed=SEED + (4 if workload == "s2" else 3) + 1000 * rank)
+        order = os.environ.get("ARP_BENCH_ORDER")  # diagnostic: the same cloud with its atoms in another input order
+        if order:
+            import numpy as np
+            n = len(rec["x"])
+            if order == "random":
+                perm = np.random.default_rng(1).permutation(n)
+            else:  # "cell": sorted by 6.5 A cell, x fastest (the order the grid build produces)
+                perm = np.lexsort((np.floor(rec["x"] / 6.5), np.floor(rec["y"] / 6.5), np.floor(rec["z"] / 6.5)))
+            rec = {k: (v[perm] if isinstance(v, np.ndarray) and len(v) == n else v) for k, v in rec.items()}
         return aa.Structure.from_records(rec, hierarchy=True).soa("/")
 
     def batch(total):  # this rank's longest-first share of the batch, as one resident pack (packs of <= 65535 models)
