@@ -487,6 +487,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
     __shared__ LdsParams prm;
     __shared__ WaveLds<kEmit> wl[kWavesPerBlock];
     __shared__ BlockLds bl;
+    const unsigned long long n = min(result[3] * kDeferChunk, tg.defer_cap);  // result[3] counts list chunks
+    if (n == 0ull) {  // nothing was deferred (no hydrogens, no close CYS SG pair): no parameter tables, no hole
+        if (threadIdx.x == 0) hole_list[blockIdx.x] = make_ulonglong2(0ull, 0ull);
+        return;
+    }
     load_lds_params(prm, dprm, nullptr);
     if (threadIdx.x == 0) {
         bl.alloc_state = kAllocEmpty | kChunkRecords;
@@ -495,7 +500,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wflags = (dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u;
-    const unsigned long long n = min(result[3] * kDeferChunk, tg.defer_cap);  // result[3] counts list chunks
     for (unsigned long long e0 = ((unsigned long long)blockIdx.x * kWavesPerBlock + wave) * 64ull; e0 < n; e0 += (unsigned long long)gridDim.x * kWavesPerBlock * 64ull) {
         uint2 ent = make_uint2(0xFFFFFFFFu, 0u);
         if (e0 + lane < n) ent = tg.defer_list[e0 + lane];
