@@ -38,9 +38,12 @@ constexpr int kEmitWavesPerSimd = ARP_EMIT_WPS;   // register budget of the emit
 constexpr uint32_t kEmitBlocks = 128u * ARP_EMIT_WPS;  // emit mode: blocks of 8 waves, ARP_EMIT_WPS waves per SIMD
 constexpr uint32_t kGrab = 1;              // wave-tasks drawn per atomic
 #ifndef ARP_CHUNK_RECORDS
-#define ARP_CHUNK_RECORDS 2048
+#define ARP_CHUNK_RECORDS 4096
 #endif
-constexpr uint32_t kChunkRecords = ARP_CHUNK_RECORDS;    // records per global allocation (one device atomic each)
+// records per global allocation (one device atomic each).  The wave whose allocation crosses the end of the block's chunk fetches the
+// next one while the block's other waves sleep: 2048 -> 4096 halves those stalls (emit 221 -> 208 us); 8192 gains 2 us more and costs
+// the fix-up 8 us (holes grow with the chunk).
+constexpr uint32_t kChunkRecords = ARP_CHUNK_RECORDS;
 
 template <int MODE>
 struct WaveLds {                                  // per-wave LDS working set
@@ -329,7 +332,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
     // Task distribution: blocks b and b+8 share an XCD (and its private L2), so block group (b mod 8) owns one contiguous
     // eighth of the task range -- the windows its waves stage come out of that L2 -- and inside a group the waves draw
     // kGrab tasks at a time from the group's counter, which evens out the very different costs of surface and core tasks.
-    const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
+    const uint32_t n_groups = min(8u, gridDim.x);
+    const uint32_t group = blockIdx.x % n_groups;
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
     uint32_t *ctr = task_ctr + (MODE * 8 + group) * kTaskCtrStride;
     uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); emit mode carries them across tasks
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
     uint32_t t0 = g_lo + ((blockIdx.x / n_groups) * kWavesPerBlock + wave) * kGrab;
 #pragma unroll 1
     for (;; ) {
-    if (t0 >= g_hi) break;
+    if (t0 >= g_hi) break;  // (moving on to the next group's counter instead of retiring was measured: +12 % -- the loop-variant range costs registers)
     const uint32_t t1 = min(t0 + kGrab, g_hi);
 #pragma unroll 1
     for (uint32_t t = t0; t < t1; ++t) {
@@ -393,7 +397,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
                 const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
                 if (!__any(len != 0u)) continue;
                 wave_lds_fence();  // previous chunk fully consumed
+#if defined(ARP_NT_STAGE)   // diagnostic: staging loads marked non-temporal
+                for (uint32_t p = cs + lane; p < ce; p += 64u) {
+                    typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+                    const st_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const st_f32x4 *>(so.rec + p));
+                    w.nrec[p - cs] = make_float4(v.x, v.y, v.z, v.w);
+                }
+#else
                 for (uint32_t p = cs + lane; p < ce; p += 64u) w.nrec[p - cs] = so.rec[p];
+#endif
                 wave_lds_fence();
                 const uint32_t off = len ? j0 - cs : 0u;
 #pragma unroll 1
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
         if ((MODE == kCountTasks || MODE == kCountContacts) && lane == 0) task_count[t] = emitted;
     }
     uint32_t nxt = 0;
-    if (lane == 0) nxt = atomicAdd(ctr, kGrab);
+    if (lane == 0) nxt = atomicAdd(ctr, kGrab);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
     t0 = g_lo + group_waves * kGrab + __builtin_amdgcn_readfirstlane(nxt);
     }
     if (MODE == kFillOrdered && !PROBES) emit_epilogue(bl, hole_list + blockIdx.x, tg);  // (its hole entry is unused: sentinels only)
