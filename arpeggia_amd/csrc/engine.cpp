@@ -118,6 +118,7 @@ struct arp_context {
     uint64_t scr_dev_cap[2] = {0, 0}, scr_pin_cap[2] = {0, 0};
     arp_context *peer = nullptr;           // batch path: the second context of this device (own stream + workspace), kept across calls
     uint32_t defer_scale = 1;              // the deferred-probe list is sized defer_scale x the default; grown on overflow
+    const double *grid_x = nullptr; uint64_t grid_n = 0;  // the arrays the workspace's cell list was last built from (context_grid)
     arp_atoms last_atoms{};                // the enqueued call, kept so that arp_contacts_atomic_result can re-run it after growing a list
     arp_pair *last_out = nullptr;
     Profiler prof;
@@ -139,6 +140,7 @@ static arp_status dev_alloc(arp_context *ctx, T **p, size_t count) {
 }
 
 static void free_workspace(arp_context *ctx) {
+    ctx->grid_x = nullptr; ctx->grid_n = 0;
     for (void *p : ctx->ws_allocs) (void)hipFree(p);
     ctx->ws_allocs.clear();
     ctx->ws = Workspace{};
@@ -420,7 +422,7 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
     const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
-    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered);
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
     if (!out || capacity == 0) {
         launch_count(d, ctx->ws, ctx->stream, prof, 0, true, only);  // size query: reports ARP_ERR_CAPACITY + the count
     } else if (params->flags & ARP_FLAG_DETERMINISTIC) {
@@ -505,7 +507,7 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
                 HIP_TRY(hipMalloc((void **)&ctx->out_buf, want * sizeof(arp_pair)));
                 ctx->out_cap = want;
             }
-            launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false);
+            launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false); ctx->grid_x = d.x; ctx->grid_n = d.n;
             launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -525,7 +527,7 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     // count pass -> output size -> ordered fill or single-pass emit.  With ARP_FLAG_CONTACTS_ONLY the single-pass emitter
     // sizes the device buffer by the (cheap) candidate count, an upper bound; the ordered one needs the exact filtered counts.
     const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
-    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered);
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
     launch_count(d, ctx->ws, ctx->stream, prof, 0, false, only && ordered);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -664,7 +666,7 @@ arp_status enqueue_pack_kernels(BatchSlot &sl, const arp_params *params) {
     arp_context *ctx = sl.ctx;
     const bool only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
     Profiler *prof = nullptr;
-    launch_grid(sl.dev, ctx->ws, ctx->stream, prof, params->dist_cutoff, sl.ordered);
+    launch_grid(sl.dev, ctx->ws, ctx->stream, prof, params->dist_cutoff, sl.ordered); ctx->grid_x = nullptr; ctx->grid_n = 0;  // (a pack's grid: per-model origins)
     if (sl.ordered) {
         launch_count(sl.dev, ctx->ws, ctx->stream, prof, ctx->out_cap, true, only);
         launch_fill_ordered(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only);
@@ -948,6 +950,11 @@ extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const d
 namespace arp {
 void *context_stream(arp_context *ctx) { return (void *)ctx->stream; }
 int context_device(arp_context *ctx) { return ctx->device; }
+bool context_grid(arp_context *ctx, const double *x, uint64_t n, const GridParams **grid, const uint32_t **cell_start, const Fat **fat) {
+    if (!ctx || ctx->pending || !ctx->ws.grid || !x || ctx->grid_x != x || ctx->grid_n != n) return false;
+    *grid = ctx->ws.grid; *cell_start = ctx->ws.cell_start; *fat = ctx->ws.sorted.fat;
+    return true;
+}
 arp_status context_scratch(arp_context *ctx, int slot, uint64_t dev_bytes, uint64_t pinned_bytes, char **dev, char **pinned) {
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;

@@ -59,6 +59,10 @@ arp_status device_planes(arp_context *ctx, const DevStructure &ds, std::vector<d
 // engine.cpp: the context's stream / device and grow-only scratch (device and pinned host)
 void *context_stream(arp_context *ctx);
 int context_device(arp_context *ctx);
+struct GridParams;
+struct Fat;
+// the cell list the most recent pair pass of this context built -- valid only if that pass ran on exactly these arrays (x, n)
+bool context_grid(arp_context *ctx, const double *x, uint64_t n, const GridParams **grid, const uint32_t **cell_start, const Fat **fat);
 arp_status context_scratch(arp_context *ctx, int slot, uint64_t dev_bytes, uint64_t pinned_bytes, char **dev, char **pinned);  // slot 0 / 1: two independent grow-only blocks
 
 }  // namespace arp

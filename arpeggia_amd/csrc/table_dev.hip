@@ -122,14 +122,6 @@ __device__ inline bool compare_residues_d(const ResKeyD &a, const ResKeyD &b, bo
     return !(symmetric && a.in_r && b.in_r && a.in_l && b.in_l && a.chain_rank > b.chain_rank);
 }
 
-struct AtomsD {  // what the ring kernels read per atom
-    uint32_t n;
-    const double *x, *y, *z;
-    const uint32_t *attr, *res_ord;
-    const uint16_t *chain_rank, *model;
-    const int32_t *model_serial_of;
-};
-
 // ---- rows ------------------------------------------------------------------------------------------------------------
 // A row = {from entity, to entity, (f32) distance, interaction code}: the layout of arp_pair.  Entity = atom index, or n + ring index.
 __device__ inline void append_row(uint4 *rows, uint32_t *n_rows, uint32_t cap, uint32_t from, uint32_t to, double dist, uint32_t code) {
@@ -137,40 +129,52 @@ __device__ inline void append_row(uint4 *rows, uint32_t *n_rows, uint32_t cap, u
     if (p < cap) rows[p] = make_uint4(from, to, __float_as_uint((float)dist), code);  // mod.rs:148: distance narrowed to f32 at table build
 }
 
-// positively ionizable atoms by RESIDUE name (aromatic.rs:18): the only atoms that can make a ring-atom row
-__global__ __launch_bounds__(256) void k_pos_list(AtomsD at, uint32_t *list, uint32_t *n_list) {
-    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool hit = a < at.n && (at.attr[a] & ARP_ATTR_POS_RESN);
-    const unsigned long long m = __ballot(hit);
-    if (!m) return;
-    uint32_t base = 0;
-    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(n_list, (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (hit) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = a;
-}
-
-// get_ring_atom_contacts (complex.rs:301-352) + find_cation_pi (aromatic.rs:14-29): one block per ring, its threads sweep the
-// (short) list of candidate atoms.  The reference walks an R*-tree of all atoms around every ring centre.
-__global__ __launch_bounds__(256) void k_ring_atom(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, AtomsD at, const uint32_t *pos_list,
-                                                   const uint32_t *n_pos_ptr, double r2, uint4 *rows, uint32_t *n_rows, uint32_t cap) {
+// get_ring_atom_contacts (complex.rs:301-352) + find_cation_pi (aromatic.rs:14-29) on the pair pass's cell list.  The reference walks an
+// R*-tree of all atoms around every ring centre; here one wave per ring visits the cells its search sphere touches -- a handful of
+// x-contiguous slot runs of the cell-sorted records the engine left in its workspace (Fat: coordinates, attribute word, residue ordinal,
+// chain, original index) -- and only positively ionizable atoms by RESIDUE name (aromatic.rs:18) go on to the plane arithmetic.
+__global__ __launch_bounds__(64) void k_ring_atom(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, uint32_t n_atoms, const int32_t *model_serial_of,
+                                                  const GridParams *gp, const uint32_t *cell_start, const Fat *fat, double radius, uint4 *rows, uint32_t *n_rows,
+                                                  uint32_t cap) {
     const uint32_t e = blockIdx.x;
     if (e >= n_rings) return;
     const RingEnt ring = rings[e];
     if (!(ring.flags & 4u)) return;
     const PlaneD pl = ring_planes[ring.src_res];
     const ResKeyD rk{ring.model_serial, ring.chain_rank, ring.ord, (ring.flags & 1u) != 0u, (ring.flags & 2u) != 0u};
-    const uint32_t n_pos = *n_pos_ptr;
-    for (uint32_t k = threadIdx.x; k < n_pos; k += blockDim.x) {
-        const uint32_t a = pos_list[k];
-        const int32_t ms = at.model_serial_of[at.model[a]];
-        if (ms != ring.model_serial) continue;
-        const double q[3] = {at.x[a], at.y[a], at.z[a]};
-        const double dx = q[0] - pl.c[0], dy = q[1] - pl.c[1], dz = q[2] - pl.c[2];
-        if (!(dx * dx + dy * dy + dz * dz <= r2)) continue;  // rstar: inclusive (complex.rs:310)
-        const ResKeyD yk{ms, at.chain_rank[a], at.res_ord[a], (at.attr[a] & ARP_ATTR_LIGAND) != 0u, (at.attr[a] & ARP_ATTR_RECEPTOR) != 0u};
-        if (!compare_residues_d(rk, yk, false)) continue;
-        const double dist = point_dist_d(pl, q), theta = point_angle_d(pl, q);
-        if (theta <= 30.0 && dist <= 4.5) append_row(rows, n_rows, cap, at.n + e, a, dist, ARP_CationPi);
+    const GridParams g = *gp;
+    if (g.model_org || g.n_heavy == 0u) return;  // (a packed batch's grid never reaches the table path)
+    const double r2 = radius * radius, rho = fabs(radius) * g.inv_edge * (1.0 + 1e-9) + 1e-9;  // (the reference only ever uses the square: complex.rs:303)
+    // cells the sphere can touch, per axis: floor(f - rho) .. floor(f + rho) of the centre's cell coordinate f, clamped to the grid
+    uint32_t lo[3], hi[3];
+    const uint32_t dim[3] = {g.nx, g.ny, g.nz};
+    const double org[3] = {g.ox, g.oy, g.oz};
+    for (int k = 0; k < 3; k++) {
+        const double f = (pl.c[k] - org[k]) * g.inv_edge;
+        const double a = floor(f - rho), b = floor(f + rho);
+        if (!(b >= 0.0) || !(a <= (double)(dim[k] - 1u))) return;  // the sphere misses the grid (or a non-finite centre)
+        lo[k] = a > 0.0 ? (uint32_t)a : 0u;
+        hi[k] = b < (double)(dim[k] - 1u) ? (uint32_t)b : dim[k] - 1u;
+    }
+    const uint32_t n_models = g.nzt / (g.nz + 1u);
+    for (uint32_t m = 0; m < n_models; m++) {
+        if (model_serial_of[m] != ring.model_serial) continue;  // same serial = same model for the reference (complex.rs:96-98)
+        for (uint32_t cz = lo[2]; cz <= hi[2]; cz++)
+            for (uint32_t cy = lo[1]; cy <= hi[1]; cy++) {
+                const uint32_t row = ((m * (g.nz + 1u) + cz) * g.ny + cy) * g.nx;
+                const uint32_t s0 = cell_start[row + lo[0]], s1 = cell_start[row + hi[0] + 1u];
+                for (uint32_t p = s0 + threadIdx.x; p < s1; p += 64u) {
+                    const Fat f = fat[p];
+                    if (!(f.attr & ARP_ATTR_POS_RESN)) continue;
+                    const double q[3] = {f.x, f.y, f.z};
+                    const double dx = q[0] - pl.c[0], dy = q[1] - pl.c[1], dz = q[2] - pl.c[2];
+                    if (!(dx * dx + dy * dy + dz * dz <= r2)) continue;  // rstar: inclusive (complex.rs:310)
+                    const ResKeyD yk{ring.model_serial, f.crm & 0xFFFFu, f.res_ord, (f.attr & ARP_ATTR_LIGAND) != 0u, (f.attr & ARP_ATTR_RECEPTOR) != 0u};
+                    if (!compare_residues_d(rk, yk, false)) continue;
+                    const double dist = point_dist_d(pl, q), theta = point_angle_d(pl, q);
+                    if (theta <= 30.0 && dist <= 4.5) append_row(rows, n_rows, cap, n_atoms + e, f.orig, dist, ARP_CationPi);
+                }
+            }
     }
 }
 
@@ -351,7 +355,7 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort_ent, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
                                              (uint32_t *)nullptr, (int)n_ent, 0, 64);
     const uint64_t ring_rows_cap = 64 * n_rings + 1024;  // each ring meets a handful of cations / rings; checked below
-    uint64_t need = 2 * al(nr * sizeof(PlaneD)) + al(nr) + al(n_rings * sizeof(RingEnt)) + al(n_rings * sizeof(EntKey)) + al(n * 4) + 4096 + al((n_pairs + 1) * 4) * 2 +
+    uint64_t need = 2 * al(nr * sizeof(PlaneD)) + al(nr) + al(n_rings * sizeof(RingEnt)) + al(n_rings * sizeof(EntKey)) + 4096 + al((n_pairs + 1) * 4) * 2 +
                     al(std::max(cub_scan, cub_sort_ent)) + al(n_ent * 8) * 2 + al(n_ent * 4) * 4;
     char *dev = nullptr, *pin = nullptr;
     arp_status s = context_scratch(ctx, 0, need, al(n_rings * (sizeof(RingEnt) + sizeof(EntKey))) + 4096, &dev, &pin);
@@ -361,8 +365,7 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     uint8_t *valid = b.take<uint8_t>(nr);
     RingEnt *d_rings = b.take<RingEnt>(n_rings);
     EntKey *d_ring_keys = b.take<EntKey>(n_rings);
-    uint32_t *pos_list = b.take<uint32_t>(n);
-    uint32_t *counters = b.take<uint32_t>(64);  // [0] rows, [1] POS atoms
+    uint32_t *counters = b.take<uint32_t>(64);  // [0] rows
     uint32_t *bits = b.take<uint32_t>(n_pairs + 1), *first = b.take<uint32_t>(n_pairs + 1);
     char *cub_tmp = b.take<char>(std::max(cub_scan, cub_sort_ent));
     unsigned long long *ek0 = b.take<unsigned long long>(n_ent), *ek1 = b.take<unsigned long long>(n_ent);
@@ -427,11 +430,12 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     if (n_pairs) hipLaunchKernelGGL(k_expand_rows, grid(n_pairs, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, (const uint32_t *)first, rows, (uint32_t)rows_cap);
     TRY_HIP(hipMemcpyAsync(counters, first + (n_pairs ? n_pairs : 0), n_pairs ? sizeof(uint32_t) : 0, hipMemcpyDeviceToDevice, st));
     // f1: ring rows, appended behind the atom rows
-    AtomsD at{(uint32_t)n, ds.x, ds.y, ds.z, ds.attr, ds.res_ord, ds.chain_rank, ds.model, ds.model_serial_of};
     if (n_rings) {
-        if (n) hipLaunchKernelGGL(k_pos_list, grid(n, 256), dim3(256), 0, st, at, pos_list, counters + 1);
-        hipLaunchKernelGGL(k_ring_atom, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, at, (const uint32_t *)pos_list,
-                           (const uint32_t *)(counters + 1), dist_cutoff * dist_cutoff, rows, counters, (uint32_t)rows_cap);
+        // the cell list of the pair pass that has just run on this context, on these very arrays
+        const GridParams *grid = nullptr; const uint32_t *cell_start = nullptr; const Fat *fat = nullptr;
+        if (!context_grid(ctx, ds.x, ds.n, &grid, &cell_start, &fat)) { set_error("internal error: the context holds no cell list of this structure"); return ARP_ERR_HIP; }
+        hipLaunchKernelGGL(k_ring_atom, dim3((uint32_t)n_rings), dim3(64), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (uint32_t)n,
+                           (const int32_t *)ds.model_serial_of, grid, cell_start, fat, dist_cutoff, rows, counters, (uint32_t)rows_cap);
         hipLaunchKernelGGL(k_ring_ring, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (uint32_t)n, rows, counters,
                            (uint32_t)rows_cap);
     }

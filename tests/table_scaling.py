@@ -41,7 +41,7 @@ def c_call(threads, host):
 
 
 ref = None
-for host in (False, True):
+for host in ((False,) if os.environ.get("ARP_DEVICE_ONLY") else (False, True)):  # ARP_DEVICE_ONLY=1: skip the round-1 host assembly (profiling runs)
     for threads in (1, 16):
         c_call(threads, host)  # first call of a structure uploads it / builds its entity tables
         best = min((c_call(threads, host) for _ in range(3)), key=lambda r: r[0] + r[1])
