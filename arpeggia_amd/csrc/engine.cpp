@@ -471,6 +471,60 @@ extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_p
     return ARP_OK;
 }
 
+// Single-pass emitter into the context's reusable device buffer: ONE pass -- no count pass, no hipMalloc/hipFree per call (together
+// ~half of the latency of a PDB-sized structure).  A buffer that turns out too small only makes the pass report the size (k_fixup);
+// it is then grown and the pass repeated.  Leaves the list in ctx->out_buf[0 .. *total).
+static arp_status single_pass_into_context_buffer(arp_context *ctx, uint64_t n_atoms, const DevAtoms &d, const arp_params *params, Profiler *prof,
+                                                  unsigned long long *total_out) {
+    arp_status s;
+    // first guess: 64 records per atom (twice the all-pairs density of a protein), at most 2 GiB; a larger result costs one more pass
+    uint64_t want = std::max<uint64_t>(ctx->out_cap, std::min<uint64_t>(std::max<uint64_t>(64 * n_atoms, 1u << 16), 1u << 27));
+    unsigned long long total = 0;
+    for (int attempt = 0;; attempt++) {
+        if (ctx->out_cap < want) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+            ctx->out_buf = nullptr; ctx->out_cap = 0;
+            HIP_TRY(hipMalloc((void **)&ctx->out_buf, want * sizeof(arp_pair)));
+            ctx->out_cap = want;
+        }
+        launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false); ctx->grid_x = d.x; ctx->grid_n = d.n;
+        launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
+        total = ctx->h_result[0];
+        if (total <= ctx->out_cap) break;
+        if (attempt) { set_error("internal error: pair count changed between passes"); return ARP_ERR_HIP; }
+        want = total + total / 8;
+    }
+    *total_out = total;
+    return ARP_OK;
+}
+
+// The table path's pair pass (table.cpp get_contacts_device): device-resident inputs, the list stays in the context's buffer --
+// *data is a VIEW, valid until the next call on this context.
+arp_status arp::contacts_atomic_view(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, const arp_pair **data, uint64_t *n) {
+    *data = nullptr; *n = 0;
+    if (!atoms || atoms->location != ARP_MEM_DEVICE || !params || (params->flags & ARP_FLAG_DETERMINISTIC)) { set_error("contacts_atomic_view: bad arguments"); return ARP_ERR_BAD_INPUT; }
+    for (;;) {
+        arp_status s = check_device(ctx);
+        if (s != ARP_OK) return s;
+        if ((s = validate(atoms, params)) != ARP_OK) return s;
+        if ((s = ensure_workspace(ctx, atoms->n)) != ARP_OK) return s;
+        DevAtoms d{};
+        if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
+        if ((s = upload_params(ctx, params)) != ARP_OK) return s;
+        unsigned long long total = 0;
+        s = single_pass_into_context_buffer(ctx, atoms->n, d, params, ctx->prof.enabled ? &ctx->prof : nullptr, &total);
+        if (s == kRetryDefer) { if ((s = grow_defer_list(ctx, atoms->n)) != ARP_OK) return s; continue; }
+        if (s != ARP_OK) return s;
+        *data = ctx->out_buf; *n = total;
+        return ARP_OK;
+    }
+}
+
 static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location, arp_pairs *out);
 extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location,
                                           arp_pairs *out) {
@@ -493,31 +547,8 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
     if (out_location == ARP_MEM_HOST && !(params->flags & ARP_FLAG_DETERMINISTIC)) {
-        // Host output, single-pass emitter: ONE pass into the context's reusable device buffer -- no count pass, no
-        // hipMalloc/hipFree per call (together ~half of the latency of a PDB-sized structure).  A buffer that turns out too
-        // small only makes the pass report the size (k_fixup); it is then grown and the pass repeated.
-        // first guess: 64 records per atom (twice the all-pairs density of a protein), at most 2 GiB; a larger result costs one more pass
-        uint64_t want = std::max<uint64_t>(ctx->out_cap, std::min<uint64_t>(std::max<uint64_t>(64 * (uint64_t)atoms->n, 1u << 16), 1u << 27));
         unsigned long long total = 0;
-        for (int attempt = 0;; attempt++) {
-            if (ctx->out_cap < want) {
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                if (ctx->out_buf) (void)hipFree(ctx->out_buf);
-                ctx->out_buf = nullptr; ctx->out_cap = 0;
-                HIP_TRY(hipMalloc((void **)&ctx->out_buf, want * sizeof(arp_pair)));
-                ctx->out_cap = want;
-            }
-            launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false); ctx->grid_x = d.x; ctx->grid_n = d.n;
-            launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
-            total = ctx->h_result[0];
-            if (total <= ctx->out_cap) break;
-            if (attempt) { set_error("internal error: pair count changed between passes"); return ARP_ERR_HIP; }
-            want = total + total / 8;
-        }
+        if ((s = single_pass_into_context_buffer(ctx, atoms->n, d, params, prof, &total)) != ARP_OK) return s;
         if (total == 0) return ARP_OK;
         arp_pair *host = download_pairs(ctx, ctx->out_buf, total, &s);
         if (!host) return s;

@@ -537,12 +537,12 @@ arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *g
     dv.n = d.n; dv.x = d.x; dv.y = d.y; dv.z = d.z; dv.attr = d.attr; dv.res_ord = d.res_ord; dv.chain_rank = d.chain_rank; dv.model = d.model;
     dv.res_id = d.res_id; dv.n_res = d.n_res; dv.res_h_ptr = d.res_h_ptr; dv.res_h_idx = d.res_h_idx; dv.res_cb = d.res_cb; dv.res_sg = d.res_sg;
     dv.location = ARP_MEM_DEVICE;
-    arp_pairs pairs{};
-    if ((st = arp_contacts_atomic(ctx, &dv, &prm, ARP_MEM_DEVICE, &pairs)) != ARP_OK) return st;
+    const arp_pair *pairs = nullptr;  // a view of the context's own buffer: one pass, no allocation
+    uint64_t n_pairs = 0;
+    if ((st = contacts_atomic_view(ctx, &dv, &prm, &pairs, &n_pairs)) != ARP_OK) return st;
     lap("atomic pairs (GPU)");
     TableRowsHost rows;
-    st = device_table(ctx, d, rings, c->ring_keys, pairs.data, pairs.n, dist_cutoff, &rows);
-    arp_pairs_free(&pairs);
+    st = device_table(ctx, d, rings, c->ring_keys, pairs, n_pairs, dist_cutoff, &rows);
     if (st != ARP_OK) return st;
     lap("device table");
     // the table keeps the rows as they came back and a reference to the structure's entity book: no per-row host work here

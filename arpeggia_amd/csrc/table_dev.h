@@ -59,6 +59,8 @@ arp_status device_planes(arp_context *ctx, const DevStructure &ds, std::vector<d
 // engine.cpp: the context's stream / device and grow-only scratch (device and pinned host)
 void *context_stream(arp_context *ctx);
 int context_device(arp_context *ctx);
+// engine.cpp: the table path's pair pass -- device-resident inputs, *data = a view of the context's own pair buffer (valid until its next call)
+arp_status contacts_atomic_view(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, const arp_pair **data, uint64_t *n);
 struct GridParams;
 struct Fat;
 // the cell list the most recent pair pass of this context built -- valid only if that pass ran on exactly these arrays (x, n)
