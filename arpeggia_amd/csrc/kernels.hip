@@ -261,6 +261,7 @@ DEVFN float dist_f32(double s) {
 // ---------------------------------------------------------------------------------------------- pair search + launch
 #include "pairs.inl"
 #include "pairs_lds.inl"
+#include "pairs_hyb.inl"
 #include "pairs_blk.inl"
 #include "batch.inl"
 #include "sap.inl"

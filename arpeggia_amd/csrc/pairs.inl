@@ -190,11 +190,20 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
     Fat a, b;
     const bool all_both = !PROBES && (wflags & kWaveAllBoth);  // wave-uniform (held in a scalar register): a scalar branch, no divergence
     if (active) {
+#if defined(ARP_ABLATE) && ARP_ABLATE == 16   // timing ablation: the home operand read in lane order (coalesced, L1-resident): what would a cheap a-side buy?
+        a = fat_at<PROBES>(so.fat, (ent.x & ~63u) + lane); b = fat_at<PROBES>(so.fat, ent.y);
+#elif defined(ARP_ABLATE) && ARP_ABLATE == 17 // ... and both operands
+        a = fat_at<PROBES>(so.fat, (ent.x & ~63u) + lane); b = fat_at<PROBES>(so.fat, (ent.y & ~63u) + lane);
+#else
         a = fat_at<PROBES>(so.fat, ent.x); b = fat_at<PROBES>(so.fat, ent.y);  // the probe variants keep 64-bit addressing (inputs of any size)
+#endif
         s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
         const int o = all_both ? orient_all_both(a, b) : orient(a, b);
         valid = (s <= prm.r2) & (o != 0);  // rstar: inclusive
         swap = o == 2;
+#if defined(ARP_ABLATE) && (ARP_ABLATE == 16 || ARP_ABLATE == 17)
+        valid = (s != 12345.678) | (o == 77); swap = false;  // every survivor goes on (the operands are the wrong ones): same amount of work downstream
+#endif
     }
     unsigned long long vm = __ballot(valid);
     const uint32_t nvalid = (uint32_t)__popcll(vm);
@@ -724,6 +733,7 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 
 void launch_emit_x(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 void launch_emit_b(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
+void launch_emit_h(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only) {
     if (in.n >= kBigSlots) {  // beyond the 32-bit record offsets of the single-pass kernel: count + ordered fill with inline probes
@@ -736,6 +746,8 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     // against 240 us for this kernel), so the gather kernel stays the default.
     static const bool use_lds_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'l'; }();
     if (use_lds_kernel) { launch_emit_x(in, ws, out, capacity, st, prof); return; }
+    static const bool use_hyb_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'h'; }();
+    if (use_hyb_kernel && in.n < (1u << 26) - 64u) { launch_emit_h(in, ws, out, capacity, st, prof); return; }
     static const bool use_blk_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'b'; }();
     if (use_blk_kernel) { launch_emit_b(in, ws, out, capacity, st, prof); return; }
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
