@@ -22,7 +22,10 @@
 enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2, kCountContacts = 3 };
 //   kCountContacts  kCountTasks for ARP_FLAG_CONTACTS_ONLY: classifies, counts only the pairs with an interaction
 
-constexpr int kWavesPerBlock = 8;
+#ifndef ARP_WPB
+#define ARP_WPB 8
+#endif
+constexpr int kWavesPerBlock = ARP_WPB;   // (diagnostic builds: 7-wave blocks for 7 waves per SIMD)
 constexpr int kQueue = 128;
 #ifndef ARP_CHUNK
 #define ARP_CHUNK 256
@@ -35,7 +38,7 @@ constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each ownin
 #define ARP_EMIT_WPS 6
 #endif
 constexpr int kEmitWavesPerSimd = ARP_EMIT_WPS;   // register budget of the emit kernel: 80 VGPRs at 6, 64 at 8
-constexpr uint32_t kEmitBlocks = 128u * ARP_EMIT_WPS;  // emit mode: blocks of 8 waves, ARP_EMIT_WPS waves per SIMD
+constexpr uint32_t kEmitBlocks = (1024u * ARP_EMIT_WPS) / ARP_WPB;  // emit mode: blocks of 8 waves, ARP_EMIT_WPS waves per SIMD
 constexpr uint32_t kGrab = 1;              // wave-tasks drawn per atomic
 #ifndef ARP_CHUNK_RECORDS
 #define ARP_CHUNK_RECORDS 4096
