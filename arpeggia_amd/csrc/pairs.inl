@@ -744,15 +744,14 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
         launch_fill_ordered(in, ws, out, capacity, st, prof, contacts_only);
         return;
     }
-    // ARP_EMIT_KERNEL=lds selects k_pairs_x (pairs_lds.inl): both operands of the exact phase out of LDS.  Measured on S2 10^6 atoms
-    // (profiles/r02_emit_kernels.txt) it moves 6x less L2 traffic but runs at 3 waves per SIMD and is issue-bound there (295 us
-    // against 240 us for this kernel), so the gather kernel stays the default.
-    static const bool use_lds_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'l'; }();
-    if (use_lds_kernel) { launch_emit_x(in, ws, out, capacity, st, prof); return; }
-    static const bool use_hyb_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'h'; }();
-    if (use_hyb_kernel && in.n < (1u << 26) - 64u) { launch_emit_h(in, ws, out, capacity, st, prof); return; }
-    static const bool use_blk_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'b'; }();
-    if (use_blk_kernel) { launch_emit_b(in, ws, out, capacity, st, prof); return; }
+    // Four single-pass emit kernels exist, all parity-green (profiles/r02_emit_kernels.txt; S2 10^6 atoms): the default k_pairs_h
+    // (pairs_hyb.inl: home operand of the exact phase in LDS, 199 us), this file's k_pairs (both operands gathered, 210 us;
+    // ARP_EMIT_KERNEL=gather, and the fallback beyond k_pairs_h's 2^26 slots), k_pairs_x (=lds: both operands in LDS, 297 us) and
+    // k_pairs_b (=blk: block-cooperative, 297 us).
+    static const char emit_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] ? e[0] : 'h'; }();
+    if (emit_kernel == 'l') { launch_emit_x(in, ws, out, capacity, st, prof); return; }
+    if (emit_kernel == 'b') { launch_emit_b(in, ws, out, capacity, st, prof); return; }
+    if (emit_kernel != 'g' && in.n < (1u << 26) - 64u) { launch_emit_h(in, ws, out, capacity, st, prof); return; }
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1600)
         const char *e = getenv("ARP_EMIT_BLOCKS");

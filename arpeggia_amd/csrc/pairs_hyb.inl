@@ -1,32 +1,41 @@
-// The single-pass emitter with the HOME operand of the exact phase in LDS (ARP_EMIT_KERNEL=h).  Included by kernels.hip after
-// pairs_lds.inl, inside namespace arp.
+// The default single-pass emitter: the HOME operand of the exact phase lives in LDS.  Included by kernels.hip after pairs_lds.inl,
+// inside namespace arp.
 //
 // k_pairs<kEmit> (pairs.inl) gathers two 48-byte records per survivor, each a 64-byte line out of the L2: 3.4 GB per launch on the
 // headline input = 16 TB/s, the rate MI355X_MICROARCH.md measures for L2-served gathers.  Half of those records are the task's own 64
 // home atoms, fetched again for every batch.  Here the wave keeps them in LDS for the duration of the task (40 bytes each) and phase 2
 // reads the home side with three ds_read; queue entries shrink to 4 bytes (home lane << 26 | neighbour slot); because the home records
-// change with the task the queue is drained at every task end; and since a batch in flight now costs ten registers instead of
-// twenty-four, kHMulti batches share one gather round trip.
+// change with the task the queue is drained at every task end.
 //
-// Measured (profiles/r02_emit_kernels.txt): 250 us with one batch per round trip, 228 us with two or three -- against 247 us for
-// k_pairs at the same 4 waves per SIMD, and 209 us for k_pairs at its 6.  The 2.5 KB of home records per wave cap this kernel at 16 waves
-// per CU, and the chain of dependent round trips of a wave (not bytes, not instructions) is what sets the pace of all these kernels,
-// so the extra waves of k_pairs still win.  Parity-green under the full GPU suite; not the default.
-constexpr int kHWaves = 4;                   // waves per block (7.3 KB of LDS each + the block's 8.4 KB of decision tables)
-#ifndef ARP_H_BLOCKS_PER_CU
-#define ARP_H_BLOCKS_PER_CU 4
+// What it took to make this pay (profiles/r02_emit_kernels.txt): all these kernels are paced by the chain of dependent round trips of a
+// wave times the resident waves, so the 2.5 KB of home records per wave had to come out of the staged chunk (160 records instead of 256)
+// and the decision tables had to be shared by more waves (12-wave blocks, two per CU) to keep 6 waves per SIMD: 199 us against 210 us
+// for k_pairs (S1 181 / 188, the config-5 pack 864 / 922, contacts-only 85 / 92).  At 4 waves per SIMD the same kernel ran 250 us, 228 us
+// with kHMulti = 3 batches behind one gather round trip (the second and third batch in flight cost ten registers each, which 6 waves
+// do not have).
+#ifndef ARP_H_WAVES
+#define ARP_H_WAVES 12
 #endif
+#ifndef ARP_H_BLOCKS_PER_CU
+#define ARP_H_BLOCKS_PER_CU 2
+#endif
+#ifndef ARP_H_CHUNK
+#define ARP_H_CHUNK 160
+#endif
+constexpr uint32_t kHChunk = ARP_H_CHUNK;     // staged neighbour records per chunk
+constexpr int kHWaves = ARP_H_WAVES;         // waves per block (7-8 KB of LDS each + the block's 8.4 KB of decision tables)
 constexpr uint32_t kHBlocks = 256u * ARP_H_BLOCKS_PER_CU;
+constexpr int kHWavesPerSimd = (ARP_H_WAVES * ARP_H_BLOCKS_PER_CU) / 4;
 constexpr uint32_t kHSlotBits = 26;          // neighbour slot bits of a queue entry; the launcher routes larger inputs elsewhere
 constexpr uint32_t kHMaxSlots = (1u << kHSlotBits) - 64u;
 #ifndef ARP_H_MULTI
-#define ARP_H_MULTI 3
+#define ARP_H_MULTI 1
 #endif
 constexpr uint32_t kHMulti = ARP_H_MULTI;     // batches classified per round trip (their gathers are in flight together)
 constexpr uint32_t kHQueue = 64u * kHMulti + 64u;  // the queue fills to 64 kHMulti (+ up to 63 of the last round)
 
 struct WaveLdsH {
-    float4 nrec[kChunk + kBlock];            // f32 prefilter records of the staged chunk (+ kBlock: over-reads stay in bounds)
+    float4 nrec[kHChunk + kBlock];           // f32 prefilter records of the staged chunk (+ kBlock: over-reads stay in bounds)
     u32x4 hxy[64]; u32x4 hzm[64]; u32x2 hco[64];   // the task's home atoms: {x, y}, {z, pw, res_ord}, {crm, orig}
     uint32_t queue[kHQueue];                 // phase-1 survivors: home lane << 26 | neighbour slot
 };
@@ -72,7 +81,7 @@ DEVFN void exact_batches_h(const LdsParams &prm, WaveLdsH &w, BlockLds &bl, cons
         if (64u * k < count) exact_one_h(prm, w, bl, g[k], e[k], 64u * k + lane < count, slot0, tg, result, lane, wflags, have_res);
 }
 
-__global__ __launch_bounds__(kHWaves * 64, ARP_H_BLOCKS_PER_CU) void k_pairs_h(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so, EmitTarget tg,
+__global__ __launch_bounds__(kHWaves * 64, kHWavesPerSimd) void k_pairs_h(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so, EmitTarget tg,
                                                                                 ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     __shared__ LdsParams prm;
     __shared__ WaveLdsH wl[kHWaves];
@@ -147,8 +156,8 @@ __global__ __launch_bounds__(kHWaves * 64, ARP_H_BLOCKS_PER_CU) void k_pairs_h(D
             const uint32_t L = wave_min_u32(nonempty ? lo : 0xFFFFFFFFu), H = wave_max_u32(nonempty ? hi : 0u);
             if (L >= H) continue;
 #pragma unroll 1
-            for (uint32_t cs = L; cs < H; cs += kChunk) {
-                const uint32_t ce = min(cs + kChunk, H);
+            for (uint32_t cs = L; cs < H; cs += kHChunk) {
+                const uint32_t ce = min(cs + kHChunk, H);
                 const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
                 const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
                 if (!__any(len != 0u)) continue;
