@@ -81,10 +81,12 @@ DEVFN void exact_batches_h(const LdsParams &prm, WaveLdsH &w, BlockLds &bl, cons
         if (64u * k < count) exact_one_h(prm, w, bl, g[k], e[k], 64u * k + lane < count, slot0, tg, result, lane, wflags, have_res);
 }
 
-__global__ __launch_bounds__(kHWaves * 64, kHWavesPerSimd) void k_pairs_h(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so, EmitTarget tg,
+// WAVES per block: kHWaves for inputs that fill the chip; 4 for small ones, whose few tasks then spread over more CUs
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) void k_pairs_h(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so, EmitTarget tg,
                                                                                 ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     __shared__ LdsParams prm;
-    __shared__ WaveLdsH wl[kHWaves];
+    __shared__ WaveLdsH wl[WAVES];
     __shared__ BlockLds bl;
     load_lds_params(prm, dprm, gp);
     if (threadIdx.x == 0) {
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(kHWaves * 64, kHWavesPerSimd) void k_pairs_h(DevAto
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
     uint32_t *ctr = task_ctr + (kEmit * 8 + group) * kTaskCtrStride;
     const uint32_t queue_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)w.queue);
-    const uint32_t group_waves = ((gridDim.x - group + n_groups - 1u) / n_groups) * kHWaves;
-    uint32_t t = g_lo + (blockIdx.x / n_groups) * kHWaves + wave;
+    const uint32_t group_waves = ((gridDim.x - group + n_groups - 1u) / n_groups) * WAVES;
+    uint32_t t = g_lo + (blockIdx.x / n_groups) * WAVES + wave;
 #pragma unroll 1
     while (t < g_hi) {
         const uint32_t a = t * 64u + lane;  // this lane's home slot
@@ -213,15 +215,21 @@ __global__ __launch_bounds__(kHWaves * 64, kHWavesPerSimd) void k_pairs_h(DevAto
 // single-pass emit + hole fix-up through k_pairs_h: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit_h(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
-    const uint32_t tasks = (in.n + 63u) / 64u, want = (tasks + kHWaves - 1) / kHWaves;
-    const uint32_t nb = want < 1 ? 1 : (want > kHBlocks ? kHBlocks : want);
+    const uint32_t tasks = (in.n + 63u) / 64u;
+    const bool small = tasks < kHBlocks * (uint32_t)kHWaves;  // fewer tasks than resident waves: 4-wave blocks reach more CUs (6bft: 128 tasks)
+    const uint32_t per = small ? 4u : (uint32_t)kHWaves, want = (tasks + per - 1u) / per;
+    const uint32_t nb = want < 1 ? 1 : (want > (small ? 1536u : kHBlocks) ? (small ? 1536u : kHBlocks) : want);
     if (prof) prof->begin("pairs_emit", st);
-    hipLaunchKernelGGL(k_pairs_h, dim3(nb), dim3(kHWaves * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, (const uint32_t *)ws.cell_start,
-                       ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result);
+    if (small)
+        hipLaunchKernelGGL(k_pairs_h<4>, dim3(nb), dim3(4 * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, (const uint32_t *)ws.cell_start,
+                           ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result);
+    else
+        hipLaunchKernelGGL(k_pairs_h<kHWaves>, dim3(nb), dim3(kHWaves * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, (const uint32_t *)ws.cell_start,
+                           ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_deferred", st); }
     hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_fixup", st); }
     hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, nb + kDeferBlocks, (const GridParams *)ws.grid, tg, ws.result);
     if (prof) prof->end(st);
 }
-static_assert(kHBlocks + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");
+static_assert(kHBlocks + 384u <= kMaxHoles && 1536u + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");
