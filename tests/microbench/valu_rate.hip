@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float *out, int iters) {
@@ -40,6 +41,26 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
             asm volatile("v_add_f64 %0, %0, %0\n v_mul_f64 %1, %1, %1\n v_add_f64 %2, %2, %2\n v_mul_f64 %3, %3, %3\n"
                          "v_add_f64 %0, %0, %0\n v_mul_f64 %1, %1, %1\n v_add_f64 %2, %2, %2\n v_mul_f64 %3, %3, %3"
                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        } else if (KIND == 8) {  // 8 independent v_dot2_i32_i16
+            asm volatile("v_dot2_i32_i16 %0, %0, %0, %0\n v_dot2_i32_i16 %1, %1, %1, %1\n v_dot2_i32_i16 %2, %2, %2, %2\n v_dot2_i32_i16 %3, %3, %3, %3\n"
+                         "v_dot2_i32_i16 %4, %4, %4, %4\n v_dot2_i32_i16 %5, %5, %5, %5\n v_dot2_i32_i16 %6, %6, %6, %6\n v_dot2_i32_i16 %7, %7, %7, %7"
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if (KIND == 9) {  // 8 independent v_pk_sub_i16
+            asm volatile("v_pk_sub_i16 %0, %0, %1\n v_pk_sub_i16 %1, %1, %2\n v_pk_sub_i16 %2, %2, %3\n v_pk_sub_i16 %3, %3, %4\n"
+                         "v_pk_sub_i16 %4, %4, %5\n v_pk_sub_i16 %5, %5, %6\n v_pk_sub_i16 %6, %6, %7\n v_pk_sub_i16 %7, %7, %0"
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if (KIND == 10) {  // 8 independent v_mad_i32_i16
+            asm volatile("v_mad_i32_i16 %0, %0, %0, %0\n v_mad_i32_i16 %1, %1, %1, %1\n v_mad_i32_i16 %2, %2, %2, %2\n v_mad_i32_i16 %3, %3, %3, %3\n"
+                         "v_mad_i32_i16 %4, %4, %4, %4\n v_mad_i32_i16 %5, %5, %5, %5\n v_mad_i32_i16 %6, %6, %6, %6\n v_mad_i32_i16 %7, %7, %7, %7"
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if (KIND == 11) {  // 8 independent v_mad_i32_i24
+            asm volatile("v_mad_i32_i24 %0, %0, %0, %0\n v_mad_i32_i24 %1, %1, %1, %1\n v_mad_i32_i24 %2, %2, %2, %2\n v_mad_i32_i24 %3, %3, %3, %3\n"
+                         "v_mad_i32_i24 %4, %4, %4, %4\n v_mad_i32_i24 %5, %5, %5, %5\n v_mad_i32_i24 %6, %6, %6, %6\n v_mad_i32_i24 %7, %7, %7, %7"
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if (KIND == 12) {  // 8 independent v_dot2_f32_f16
+            asm volatile("v_dot2_f32_f16 %0, %0, %0, %0\n v_dot2_f32_f16 %1, %1, %1, %1\n v_dot2_f32_f16 %2, %2, %2, %2\n v_dot2_f32_f16 %3, %3, %3, %3\n"
+                         "v_dot2_f32_f16 %4, %4, %4, %4\n v_dot2_f32_f16 %5, %5, %5, %5\n v_dot2_f32_f16 %6, %6, %6, %6\n v_dot2_f32_f16 %7, %7, %7, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3) + (float)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7);
@@ -76,6 +97,10 @@ void run(const char *name, int n_instr) {
 int main() {
     setvbuf(stdout, NULL, _IONBF, 0);
     printf("start\n");
+    if (getenv("VALU_RATE_NEW")) {
+        run<8>("v_dot2_i32_i16 x8 indep", 8); run<9>("v_pk_sub_i16 x8 indep", 8); run<10>("v_mad_i32_i16 x8 indep", 8); run<11>("v_mad_i32_i24 x8 indep", 8); run<12>("v_dot2_f32_f16 x8 indep", 8);
+        return 0;
+    }
     run<0>("f32 fma x8 independent", 8);
     run<1>("f32 fma x8 dependent", 8);
     run<2>("u32 add x8 independent", 8);
