@@ -82,7 +82,10 @@ DEVFN void exact_batches_h(const LdsParams &prm, WaveLdsH &w, BlockLds &bl, cons
 }
 
 // WAVES per block: kHWaves for inputs that fill the chip; 4 for small ones, whose few tasks then spread over more CUs
-template <int WAVES>
+// SPLIT: 1, or 4 = a task's five window kinds are shared out over four waves ({0, 1}, {2}, {3}, {4}), or 8 = two waves per kind set on
+// alternate 16-test blocks: a small input has few tasks and each is a long chain of dependent round trips, so more waves on a
+// fraction of the chain each is what shortens the launch
+template <int WAVES, int SPLIT>
 __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) void k_pairs_h(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so, EmitTarget tg,
                                                                                 ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     __shared__ LdsParams prm;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) 
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
+    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
     const uint32_t wflags = (gp->all_both ? kWaveAllBoth : 0u) | ((dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u);
     const uint32_t have_res = in.n_res != 0u ? 1u : 0u;
     const double r2m = gp->r2m;
@@ -109,7 +112,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) 
     uint32_t t = g_lo + (blockIdx.x / n_groups) * WAVES + wave;
 #pragma unroll 1
     while (t < g_hi) {
-        const uint32_t a = t * 64u + lane;  // this lane's home slot
+        constexpr uint32_t kSubs = SPLIT == 8 ? 2u : 1u;  // SPLIT == 8: two waves per kind set, on alternate 16-test blocks
+        const uint32_t slot0 = (t / (uint32_t)SPLIT) * 64u, part = (t % (uint32_t)SPLIT) / kSubs, sub = (t % (uint32_t)SPLIT) % kSubs;
+        const int k_lo = SPLIT == 1 ? 0 : (part == 0u ? 0 : (int)part + 1), k_hi = SPLIT == 1 ? 5 : (int)part + 2;  // window kinds of this wave-task
+        const uint32_t a = slot0 + lane;  // this lane's home slot
         const bool have = a < n_heavy;
         float4 home = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t cx = 0, cy = 0, cz = 0;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) 
         const uint32_t lane_tag = lane << kHSlotBits;
         uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); drained at the end of the task
 #pragma unroll 1
-        for (int k = 0; k < 5; k++) {
+        for (int k = k_lo; k < k_hi; k++) {
             uint32_t lo = wlo[0], hi = whi[0];
 #pragma unroll
             for (int j = 1; j < 5; j++) if (k == j) { lo = wlo[j]; hi = whi[j]; }
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) 
                 wave_lds_fence();
                 const uint32_t off = len ? j0 - cs : 0u;
 #pragma unroll 1
-                for (uint32_t it0 = 0; __any(it0 < len); it0 += kBlock) {
+                for (uint32_t it0 = sub * kBlock; __any(it0 < len); it0 += kSubs * kBlock) {
                     const uint32_t wbase = it0 < len ? off + it0 : 0u;
                     const float4 *win = w.nrec + wbase;
                     uint32_t mask = 0;
@@ -197,14 +203,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) 
                         uint32_t q1 = q0 + (uint32_t)__popcll(m);
                         if (q1 >= 64u * kHMulti) {
                             q1 -= 64u * kHMulti;
-                            exact_batches_h(prm, w, bl, so, q1, 64u * kHMulti, t * 64u, tg, result, lane, wflags, have_res);
+                            exact_batches_h(prm, w, bl, so, q1, 64u * kHMulti, slot0, tg, result, lane, wflags, have_res);
                         }
                         qlen = q1;
                     }
                 }
             }
         }
-        if (qlen) exact_batches_h(prm, w, bl, so, 0u, qlen, t * 64u, tg, result, lane, wflags, have_res);  // the home records go with the task: drain
+        if (qlen) exact_batches_h(prm, w, bl, so, 0u, qlen, slot0, tg, result, lane, wflags, have_res);  // the home records go with the task: drain
         uint32_t nxt = 0;
         if (lane == 0) nxt = atomicAdd(ctr, 1u);
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt);
@@ -216,16 +222,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) 
 void launch_emit_h(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t tasks = (in.n + 63u) / 64u;
-    const bool small = tasks < kHBlocks * (uint32_t)kHWaves;  // fewer tasks than resident waves: 4-wave blocks reach more CUs (6bft: 128 tasks)
-    const uint32_t per = small ? 4u : (uint32_t)kHWaves, want = (tasks + per - 1u) / per;
-    const uint32_t nb = want < 1 ? 1 : (want > (small ? 1536u : kHBlocks) ? (small ? 1536u : kHBlocks) : want);
+    // fewer tasks than resident waves: 4-wave blocks reach more CUs, and every task is shared out over four waves (6bft: 128 tasks)
+    const bool small = tasks < kHBlocks * (uint32_t)kHWaves, tiny = tasks < 768u;   // tiny: even 8 waves per task leave CUs idle
+    const uint32_t split = tiny ? 8u : (small ? 4u : 1u);
+    const uint32_t per = small ? 4u : (uint32_t)kHWaves, cap = small ? 1536u : kHBlocks, want = (split * tasks + per - 1u) / per;
+    const uint32_t nb = want < 1 ? 1 : (want > cap ? cap : want);
     if (prof) prof->begin("pairs_emit", st);
-    if (small)
-        hipLaunchKernelGGL(k_pairs_h<4>, dim3(nb), dim3(4 * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, (const uint32_t *)ws.cell_start,
-                           ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result);
-    else
-        hipLaunchKernelGGL(k_pairs_h<kHWaves>, dim3(nb), dim3(kHWaves * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, (const uint32_t *)ws.cell_start,
-                           ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result);
+#define ARP_LAUNCH_H(W, S) hipLaunchKernelGGL((k_pairs_h<W, S>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
+                                              (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
+    if (tiny) ARP_LAUNCH_H(4, 8);
+    else if (small) ARP_LAUNCH_H(4, 4);
+    else ARP_LAUNCH_H(kHWaves, 1);
+#undef ARP_LAUNCH_H
     if (prof) { prof->end(st); prof->begin("pairs_deferred", st); }
     hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result);
     if (prof) { prof->end(st); prof->begin("pairs_fixup", st); }
