@@ -222,16 +222,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kHWaves ? kHWavesPerSimd : 4) 
 void launch_emit_h(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t tasks = (in.n + 63u) / 64u;
-    // fewer tasks than resident waves: 4-wave blocks reach more CUs, and every task is shared out over four waves (6bft: 128 tasks)
-    const bool small = tasks < kHBlocks * (uint32_t)kHWaves, tiny = tasks < 768u;   // tiny: even 8 waves per task leave CUs idle
-    const uint32_t split = tiny ? 8u : (small ? 4u : 1u);
-    const uint32_t per = small ? 4u : (uint32_t)kHWaves, cap = small ? 1536u : kHBlocks, want = (split * tasks + per - 1u) / per;
+    // few tasks: 4-wave blocks reach more CUs, and every task is shared out over four or eight waves (6bft: 128 tasks)
+    // measured on S2 clouds (tests/debug/sweep_split.sh): 8 waves per task win below ~800 tasks, 4 up to ~3000, whole tasks in 12-wave blocks beyond
+    const bool small = tasks < 3072u, tiny = tasks < 768u;
+    static const int force = [] { const char *e = getenv("ARP_H_SPLIT"); return e ? atoi(e) : 0; }();  // experiments: 1 / 4 / 8 in 4-wave blocks, -1 = the 12-wave kernel
+    uint32_t split = tiny ? 8u : (small ? 4u : 1u);
+    bool small_blocks = small;
+    if (force == 1 || force == 4 || force == 8) { split = (uint32_t)force; small_blocks = true; }
+    if (force == -1) { split = 1u; small_blocks = false; }
+    const uint32_t per = small_blocks ? 4u : (uint32_t)kHWaves, cap = small_blocks ? 1536u : kHBlocks, want = (split * tasks + per - 1u) / per;
     const uint32_t nb = want < 1 ? 1 : (want > cap ? cap : want);
     if (prof) prof->begin("pairs_emit", st);
 #define ARP_LAUNCH_H(W, S) hipLaunchKernelGGL((k_pairs_h<W, S>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
                                               (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
-    if (tiny) ARP_LAUNCH_H(4, 8);
-    else if (small) ARP_LAUNCH_H(4, 4);
+    if (small_blocks && split == 8u) ARP_LAUNCH_H(4, 8);
+    else if (small_blocks && split == 4u) ARP_LAUNCH_H(4, 4);
+    else if (small_blocks) ARP_LAUNCH_H(4, 1);
     else ARP_LAUNCH_H(kHWaves, 1);
 #undef ARP_LAUNCH_H
     if (prof) { prof->end(st); prof->begin("pairs_deferred", st); }
