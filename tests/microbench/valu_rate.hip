@@ -57,6 +57,18 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
             asm volatile("v_mad_i32_i24 %0, %0, %0, %0\n v_mad_i32_i24 %1, %1, %1, %1\n v_mad_i32_i24 %2, %2, %2, %2\n v_mad_i32_i24 %3, %3, %3, %3\n"
                          "v_mad_i32_i24 %4, %4, %4, %4\n v_mad_i32_i24 %5, %5, %5, %5\n v_mad_i32_i24 %6, %6, %6, %6\n v_mad_i32_i24 %7, %7, %7, %7"
                          : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if (KIND == 13) {  // 8 independent v_dot2c_f32_f16 (VOP2 form: accumulates into its destination)
+            asm volatile("v_dot2c_f32_f16 %0, %1, %2\n v_dot2c_f32_f16 %1, %2, %3\n v_dot2c_f32_f16 %2, %3, %4\n v_dot2c_f32_f16 %3, %4, %5\n"
+                         "v_dot2c_f32_f16 %4, %5, %6\n v_dot2c_f32_f16 %5, %6, %7\n v_dot2c_f32_f16 %6, %7, %0\n v_dot2c_f32_f16 %7, %0, %1"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (KIND == 14) {  // 8 independent v_dot2c_i32_i16 (VOP2 form)
+            asm volatile("v_dot2c_i32_i16 %0, %1, %2\n v_dot2c_i32_i16 %1, %2, %3\n v_dot2c_i32_i16 %2, %3, %4\n v_dot2c_i32_i16 %3, %4, %5\n"
+                         "v_dot2c_i32_i16 %4, %5, %6\n v_dot2c_i32_i16 %5, %6, %7\n v_dot2c_i32_i16 %6, %7, %0\n v_dot2c_i32_i16 %7, %0, %1"
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if (KIND == 15) {  // 8 v_fmac_f32 (VOP2) independent
+            asm volatile("v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %4\n v_fmac_f32 %3, %4, %5\n"
+                         "v_fmac_f32 %4, %5, %6\n v_fmac_f32 %5, %6, %7\n v_fmac_f32 %6, %7, %0\n v_fmac_f32 %7, %0, %1"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         } else if (KIND == 12) {  // 8 independent v_dot2_f32_f16
             asm volatile("v_dot2_f32_f16 %0, %0, %0, %0\n v_dot2_f32_f16 %1, %1, %1, %1\n v_dot2_f32_f16 %2, %2, %2, %2\n v_dot2_f32_f16 %3, %3, %3, %3\n"
                          "v_dot2_f32_f16 %4, %4, %4, %4\n v_dot2_f32_f16 %5, %5, %5, %5\n v_dot2_f32_f16 %6, %6, %6, %6\n v_dot2_f32_f16 %7, %7, %7, %7"
@@ -98,7 +110,7 @@ int main() {
     setvbuf(stdout, NULL, _IONBF, 0);
     printf("start\n");
     if (getenv("VALU_RATE_NEW")) {
-        run<8>("v_dot2_i32_i16 x8 indep", 8); run<9>("v_pk_sub_i16 x8 indep", 8); run<10>("v_mad_i32_i16 x8 indep", 8); run<11>("v_mad_i32_i24 x8 indep", 8); run<12>("v_dot2_f32_f16 x8 indep", 8);
+        run<8>("v_dot2_i32_i16 x8 indep", 8); run<9>("v_pk_sub_i16 x8 indep", 8); run<10>("v_mad_i32_i16 x8 indep", 8); run<11>("v_mad_i32_i24 x8 indep", 8); run<12>("v_dot2_f32_f16 x8 indep", 8); run<13>("v_dot2c_f32_f16 x8 (VOP2)", 8); run<14>("v_dot2c_i32_i16 x8 (VOP2)", 8); run<15>("v_fmac_f32 x8 (VOP2)", 8);
         return 0;
     }
     run<0>("f32 fma x8 independent", 8);
