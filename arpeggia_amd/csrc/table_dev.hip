@@ -179,9 +179,18 @@ __global__ __launch_bounds__(64) void k_ring_atom(uint32_t n_rings, const RingEn
 }
 
 // get_ring_ring_contacts (complex.rs:354-405) + find_pi_pi (aromatic.rs:33-64): ordered ring pairs, k1 in the ligand set, k2 in
-// the receptor set
-__global__ __launch_bounds__(256) void k_ring_ring(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, uint32_t n_atoms, uint4 *rows, uint32_t *n_rows,
-                                                   uint32_t cap) {
+// the receptor set.  The sweep over the other rings reads a packed {centre, model serial | flags} record per ring (32 bytes, coalesced);
+// the plane and the ring entry are gathered only for the few rings within 6 A.
+struct RingPoint { double c[3]; int32_t model_serial; uint32_t flags; };
+__global__ __launch_bounds__(256) void k_ring_points(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, RingPoint *pts) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rings) return;
+    const RingEnt k = rings[e];
+    const PlaneD p = ring_planes[k.src_res];
+    pts[e] = RingPoint{{p.c[0], p.c[1], p.c[2]}, k.model_serial, k.flags};
+}
+__global__ __launch_bounds__(256) void k_ring_ring(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, const RingPoint *pts, uint32_t n_atoms, uint4 *rows,
+                                                   uint32_t *n_rows, uint32_t cap) {
     const uint32_t e1 = blockIdx.x;
     if (e1 >= n_rings) return;
     const RingEnt k1 = rings[e1];
@@ -189,12 +198,13 @@ __global__ __launch_bounds__(256) void k_ring_ring(uint32_t n_rings, const RingE
     const PlaneD p1 = ring_planes[k1.src_res];
     const ResKeyD r1{k1.model_serial, k1.chain_rank, k1.ord, (k1.flags & 1u) != 0u, (k1.flags & 2u) != 0u};
     for (uint32_t e2 = threadIdx.x; e2 < n_rings; e2 += blockDim.x) {
-        const RingEnt k2 = rings[e2];
-        if (!(k2.flags & 4u) || !(k2.flags & 2u) || k2.model_serial != k1.model_serial) continue;
-        const PlaneD p2 = ring_planes[k2.src_res];
-        const double v[3] = {p1.c[0] - p2.c[0], p1.c[1] - p2.c[1], p1.c[2] - p2.c[2]};
+        const RingPoint q = pts[e2];
+        if (!(q.flags & 4u) || !(q.flags & 2u) || q.model_serial != k1.model_serial) continue;
+        const double v[3] = {p1.c[0] - q.c[0], p1.c[1] - q.c[1], p1.c[2] - q.c[2]};
         const double dist = norm3d(v);
         if (!(dist <= 6.0)) continue;
+        const RingEnt k2 = rings[e2];
+        const PlaneD p2 = ring_planes[k2.src_res];
         const ResKeyD r2k{k2.model_serial, k2.chain_rank, k2.ord, (k2.flags & 1u) != 0u, (k2.flags & 2u) != 0u};
         if (!compare_residues_d(r1, r2k, true)) continue;
         const double theta = point_angle_d(p1, p2.c), dih = plane_dihedral_d(p1, p2);
@@ -355,7 +365,7 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort_ent, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
                                              (uint32_t *)nullptr, (int)n_ent, 0, 64);
     const uint64_t ring_rows_cap = 64 * n_rings + 1024;  // each ring meets a handful of cations / rings; checked below
-    uint64_t need = 2 * al(nr * sizeof(PlaneD)) + al(nr) + al(n_rings * sizeof(RingEnt)) + al(n_rings * sizeof(EntKey)) + 4096 + al((n_pairs + 1) * 4) * 2 +
+    uint64_t need = 2 * al(nr * sizeof(PlaneD)) + al(nr) + al(n_rings * sizeof(RingEnt)) + al(n_rings * sizeof(EntKey)) + al(n_rings * 32) + 4096 + al((n_pairs + 1) * 4) * 2 +
                     al(std::max(cub_scan, cub_sort_ent)) + al(n_ent * 8) * 2 + al(n_ent * 4) * 4;
     char *dev = nullptr, *pin = nullptr;
     arp_status s = context_scratch(ctx, 0, need, al(n_rings * (sizeof(RingEnt) + sizeof(EntKey))) + 4096, &dev, &pin);
@@ -365,6 +375,7 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     uint8_t *valid = b.take<uint8_t>(nr);
     RingEnt *d_rings = b.take<RingEnt>(n_rings);
     EntKey *d_ring_keys = b.take<EntKey>(n_rings);
+    RingPoint *ring_pts = b.take<RingPoint>(n_rings);
     uint32_t *counters = b.take<uint32_t>(64);  // [0] rows
     uint32_t *bits = b.take<uint32_t>(n_pairs + 1), *first = b.take<uint32_t>(n_pairs + 1);
     char *cub_tmp = b.take<char>(std::max(cub_scan, cub_sort_ent));
@@ -432,11 +443,12 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     // f1: ring rows, appended behind the atom rows
     if (n_rings) {
         // the cell list of the pair pass that has just run on this context, on these very arrays
-        const GridParams *grid = nullptr; const uint32_t *cell_start = nullptr; const Fat *fat = nullptr;
-        if (!context_grid(ctx, ds.x, ds.n, &grid, &cell_start, &fat)) { set_error("internal error: the context holds no cell list of this structure"); return ARP_ERR_HIP; }
+        const GridParams *gridp = nullptr; const uint32_t *cell_start = nullptr; const Fat *fat = nullptr;
+        if (!context_grid(ctx, ds.x, ds.n, &gridp, &cell_start, &fat)) { set_error("internal error: the context holds no cell list of this structure"); return ARP_ERR_HIP; }
         hipLaunchKernelGGL(k_ring_atom, dim3((uint32_t)n_rings), dim3(64), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (uint32_t)n,
-                           (const int32_t *)ds.model_serial_of, grid, cell_start, fat, dist_cutoff, rows, counters, (uint32_t)rows_cap);
-        hipLaunchKernelGGL(k_ring_ring, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (uint32_t)n, rows, counters,
+                           (const int32_t *)ds.model_serial_of, gridp, cell_start, fat, dist_cutoff, rows, counters, (uint32_t)rows_cap);
+        hipLaunchKernelGGL(k_ring_points, grid(n_rings, 256), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, ring_pts);
+        hipLaunchKernelGGL(k_ring_ring, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (const RingPoint *)ring_pts, (uint32_t)n, rows, counters,
                            (uint32_t)rows_cap);
     }
     uint32_t n_rows = 0;
