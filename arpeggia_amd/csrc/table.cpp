@@ -486,6 +486,9 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
         TBL_HIP(hipMemcpyAsync(d.block, pin, total, hipMemcpyHostToDevice, st));
         TBL_HIP(hipStreamSynchronize(st));  // (the pinned block is scratch: reused by the table pass below)
         d.n = n; d.n_res = nr; d.n_h = nh;
+        d.n_chains = (uint32_t)s->chain_ids.size(); d.n_models = (uint32_t)nm;
+        d.any_icode = false;
+        for (uint64_t a = 1; a < n && !d.any_icode; a++) d.any_icode = c->atom_keys[a].icode != c->atom_keys[0].icode;  // (rings carry their residue's: the same values)
         d.attr_groups = groups;
     } else if (d.attr_groups != groups) {
         TBL_HIP(hipMemcpyAsync(d.attr, s->attr.data(), n * 4, hipMemcpyHostToDevice, st));

@@ -38,6 +38,8 @@ struct DevStructure {
     EntKey *ent_key = nullptr;           // per atom
     uint32_t *model_rank = nullptr;      // per model ordinal
     int32_t *model_serial_of = nullptr;  // per model ordinal
+    uint32_t n_chains = 0, n_models = 0;  // distinct chain ids / models of the structure (widths of the sort keys)
+    bool any_icode = false;              // some atom carries an insertion code (otherwise that sort pass is skipped)
     std::string attr_groups;             // the chain groups the resident attr words were built for
 };
 

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t n_items, uint32_t *v) {
 
 struct SortTables {
     uint8_t name_rank[32];   // interaction code -> rank of its name (the column is a string in the reference)
+    uint32_t rank_bits, chain_bits;   // widths of an entity rank / a chain rank in the merged keys
 };
 __global__ __launch_bounds__(256) void k_row_key(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, int pass, uint32_t n_atoms, const EntKey *atom_keys,
                                                  const EntKey *ring_keys, const uint32_t *ent_rank, const uint16_t *chain_rank, const uint16_t *model, const uint32_t *model_rank,
@@ -281,9 +282,11 @@ __global__ __launch_bounds__(256) void k_row_key(uint32_t n_rows, const uint4 *r
         case 1: k = ((unsigned long long)ins_of(r.x) << 32) | ins_of(r.y); break;                         // from_insertion, to_insertion
         case 2: k = ((unsigned long long)ent_rank[r.y] << 5) | tb.name_rank[r.w & 31u]; break;            // to_resi, to_altloc, to_atomi, interaction
         case 3: k = ent_rank[r.x]; break;                                                                 // from_resi, from_altloc, from_atomi
-        default: {                                                                                        // model, from_chain, to_chain
+        default: {                                                                                        // model, from_chain, to_chain (pass 4) ...
             const uint32_t mr = r.x < n_atoms ? model_rank[model[r.x]] : rings[r.x - n_atoms].model_rank;
-            k = ((unsigned long long)mr << 32) | ((unsigned long long)chain_of(r.x) << 16) | chain_of(r.y);
+            k = ((((unsigned long long)mr << tb.chain_bits) | chain_of(r.x)) << tb.chain_bits) | chain_of(r.y);
+            if (pass >= 5) k = (k << tb.rank_bits) | ent_rank[r.x];                                       // ... + the keys of pass 3 (pass 5)
+            if (pass == 6) k = (k << (tb.rank_bits + 5u)) | ((unsigned long long)ent_rank[r.y] << 5) | tb.name_rank[r.w & 31u];  // ... + those of pass 2 (pass 6)
         }
     }
     key[p] = k;
@@ -466,14 +469,28 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     }
     if (n_rows) {
         hipLaunchKernelGGL(k_iota, grid(n_rows, 256), dim3(256), 0, st, n_rows, perm0);
-        static const int end_bit[5] = {32, 64, 37, 32, 64};
+        // Least significant key first: distance; the insertion codes (skipped when no atom carries one: a constant key); then the entity
+        // ranks, interaction, chains and model -- as ONE key when their actual widths fit 64 bits, else as two or three.
+        auto bits = [](uint64_t v) { uint32_t b = 1; while (b < 32 && (1ull << b) < v) b++; return b; };  // width that holds 0 .. v-1
+        tb.rank_bits = bits(n_ent); tb.chain_bits = bits(std::max<uint64_t>(ds.n_chains, 1));
+        const uint32_t model_bits = bits(std::max<uint64_t>(ds.n_models, 1)), top = model_bits + 2 * tb.chain_bits;
+        int plan[5], end_bit[5], n_pass = 0;
+        plan[n_pass] = 0; end_bit[n_pass++] = 32;
+        if (ds.any_icode) { plan[n_pass] = 1; end_bit[n_pass++] = 64; }
+        if (top + 2 * tb.rank_bits + 5 <= 64) { plan[n_pass] = 6; end_bit[n_pass++] = (int)(top + 2 * tb.rank_bits + 5); }
+        else {
+            plan[n_pass] = 2; end_bit[n_pass++] = (int)(tb.rank_bits + 5);
+            if (top + tb.rank_bits <= 64) { plan[n_pass] = 5; end_bit[n_pass++] = (int)(top + tb.rank_bits); }
+            else { plan[n_pass] = 3; end_bit[n_pass++] = (int)tb.rank_bits; plan[n_pass] = 4; end_bit[n_pass++] = (int)top; }
+        }
         uint32_t *pin_ = perm0, *pout = perm1;
-        for (int pass = 0; pass < 5; pass++) {
+        for (int q = 0; q < n_pass; q++) {
+            const int pass = plan[q];
             hipLaunchKernelGGL(k_row_key, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, pass, (uint32_t)n, (const EntKey *)ds.ent_key,
                                (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint16_t *)ds.chain_rank, (const uint16_t *)ds.model, (const uint32_t *)ds.model_rank,
                                (const RingEnt *)d_rings, tb, rk0);
             size_t tmp = cub_sort_rows;
-            TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp2, tmp, (const unsigned long long *)rk0, rk1, (const uint32_t *)pin_, pout, (int)n_rows, 0, end_bit[pass], st));
+            TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp2, tmp, (const unsigned long long *)rk0, rk1, (const uint32_t *)pin_, pout, (int)n_rows, 0, end_bit[q], st));
             std::swap(pin_, pout);
         }
         hipLaunchKernelGGL(k_finish_rows, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, (uint32_t)n, (const uint32_t *)ds.atom_sc_src,
