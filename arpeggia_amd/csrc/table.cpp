@@ -311,7 +311,7 @@ struct TableCache {
     std::vector<uint32_t> ring_model_rank;
     std::shared_ptr<EntityBook> book;
     DevStructure dev;
-    ~TableCache() { if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); } }
+    ~TableCache() { if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); } }
 };
 void free_table_cache(void *p) { delete (TableCache *)p; }
 uint32_t be32(const char *p) { return ((uint32_t)(unsigned char)p[0] << 24) | ((uint32_t)(unsigned char)p[1] << 16) | ((uint32_t)(unsigned char)p[2] << 8) | (uint32_t)(unsigned char)p[3]; }
@@ -452,7 +452,7 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
     TBL_HIP(hipSetDevice(device));
     const uint64_t n = s->n, nr = s->residues.size(), nh = s->res_h_idx.size(), nm = c->model_rank.size();
     if (!d.block || d.device != device) {
-        if (d.block) { (void)hipSetDevice(d.device); (void)hipFree(d.block); (void)hipSetDevice(device); d.block = nullptr; }
+        if (d.block) { (void)hipSetDevice(d.device); (void)hipFree(d.block); if (d.derived) (void)hipFree(d.derived); (void)hipSetDevice(device); d.block = nullptr; d.derived = nullptr; }
         struct Seg { const void *src; uint64_t bytes; void **dst; };
         Seg seg[] = {{s->x.data(), n * 8, (void **)&d.x}, {s->y.data(), n * 8, (void **)&d.y}, {s->z.data(), n * 8, (void **)&d.z},
                      {s->attr.data(), n * 4, (void **)&d.attr}, {s->res_ord.data(), n * 4, (void **)&d.res_ord}, {s->res_id.data(), n * 4, (void **)&d.res_id},
@@ -535,7 +535,7 @@ arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *g
     arp_default_params(&prm);
     prm.vdw_comp = vdw_comp; prm.dist_cutoff = dist_cutoff;
     prm.flags |= ARP_FLAG_CONTACTS_ONLY;  // only pairs with an interaction become rows
-    const DevStructure &d = c->dev;
+    DevStructure &d = c->dev;
     arp_atoms dv{};
     dv.n = d.n; dv.x = d.x; dv.y = d.y; dv.z = d.z; dv.attr = d.attr; dv.res_ord = d.res_ord; dv.chain_rank = d.chain_rank; dv.model = d.model;
     dv.res_id = d.res_id; dv.n_res = d.n_res; dv.res_h_ptr = d.res_h_ptr; dv.res_h_idx = d.res_h_idx; dv.res_cb = d.res_cb; dv.res_sg = d.res_sg;

@@ -38,6 +38,9 @@ struct DevStructure {
     EntKey *ent_key = nullptr;           // per atom
     uint32_t *model_rank = nullptr;      // per model ordinal
     int32_t *model_serial_of = nullptr;  // per model ordinal
+    // derived once per structure by the first device_table call (they depend on the structure alone): the fitted planes and the entity ranks
+    char *derived = nullptr;             // one allocation
+    void *ring_pl = nullptr, *sc_pl = nullptr; uint8_t *pl_valid = nullptr; uint32_t *ent_rank = nullptr; uint64_t derived_n_ent = 0;
     uint32_t n_chains = 0, n_models = 0;  // distinct chain ids / models of the structure (widths of the sort keys)
     bool any_icode = false;              // some atom carries an insertion code (otherwise that sort pass is skipped)
     std::string attr_groups;             // the chain groups the resident attr words were built for
@@ -53,7 +56,7 @@ struct TableRowsHost {   // what comes back: rows in final order (plain arrays: 
 
 // Runs the whole device pipeline for one structure.  `pairs_dev` = contacts-only pair list on the device (arp_contacts_atomic,
 // ARP_MEM_DEVICE).  Returns ARP_ERR_NO_RINGS etc. like arp_get_contacts.
-arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vector<RingEnt> &rings, const std::vector<EntKey> &ring_keys,
+arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<RingEnt> &rings, const std::vector<EntKey> &ring_keys,
                         const arp_pair *pairs_dev, uint64_t n_pairs, double dist_cutoff, TableRowsHost *out);
 // the planes the device fitted, for tests (PHE4 of 1ubq: residues.rs:355-372): 12 doubles per residue {ring c, ring n, sc c, sc n} + validity bits
 arp_status device_planes(arp_context *ctx, const DevStructure &ds, std::vector<double> *planes, std::vector<uint8_t> *valid);

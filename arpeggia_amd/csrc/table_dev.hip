@@ -347,7 +347,7 @@ arp_status device_planes(arp_context *ctx, const DevStructure &ds, std::vector<d
     return ARP_OK;
 }
 
-arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vector<RingEnt> &rings, const std::vector<EntKey> &ring_keys, const arp_pair *pairs_dev,
+arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<RingEnt> &rings, const std::vector<EntKey> &ring_keys, const arp_pair *pairs_dev,
                         uint64_t n_pairs, double dist_cutoff, TableRowsHost *out) {
     hipStream_t st = (hipStream_t)context_stream(ctx);
     const bool timing = getenv("ARP_TIMING") != nullptr;
@@ -374,8 +374,18 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     arp_status s = context_scratch(ctx, 0, need, al(n_rings * (sizeof(RingEnt) + sizeof(EntKey))) + 4096, &dev, &pin);
     if (s != ARP_OK) return s;
     Bump b{dev, 0, need};
-    PlaneD *ring_pl = b.take<PlaneD>(nr), *sc_pl = b.take<PlaneD>(nr);
-    uint8_t *valid = b.take<uint8_t>(nr);
+    // planes and entity ranks depend on the structure alone: computed by the first call, kept with the resident copy
+    const bool derive = !ds.derived || ds.derived_n_ent != n_ent;
+    if (derive) {
+        if (ds.derived) { (void)hipFree(ds.derived); ds.derived = nullptr; }
+        const uint64_t bytes = 2 * al(nr * sizeof(PlaneD)) + al(nr) + al(n_ent * 4) + 1024;
+        TRY_HIP(hipMalloc((void **)&ds.derived, bytes));
+        Bump db{ds.derived, 0, bytes};
+        ds.ring_pl = db.take<PlaneD>(nr); ds.sc_pl = db.take<PlaneD>(nr); ds.pl_valid = db.take<uint8_t>(nr); ds.ent_rank = db.take<uint32_t>(n_ent);
+        ds.derived_n_ent = n_ent;
+    }
+    PlaneD *ring_pl = (PlaneD *)ds.ring_pl, *sc_pl = (PlaneD *)ds.sc_pl;
+    uint8_t *valid = ds.pl_valid;
     RingEnt *d_rings = b.take<RingEnt>(n_rings);
     EntKey *d_ring_keys = b.take<EntKey>(n_rings);
     RingPoint *ring_pts = b.take<RingPoint>(n_rings);
@@ -383,7 +393,7 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     uint32_t *bits = b.take<uint32_t>(n_pairs + 1), *first = b.take<uint32_t>(n_pairs + 1);
     char *cub_tmp = b.take<char>(std::max(cub_scan, cub_sort_ent));
     unsigned long long *ek0 = b.take<unsigned long long>(n_ent), *ek1 = b.take<unsigned long long>(n_ent);
-    uint32_t *eid0 = b.take<uint32_t>(n_ent), *eid1 = b.take<uint32_t>(n_ent), *eflag = b.take<uint32_t>(n_ent), *ent_rank = b.take<uint32_t>(n_ent);
+    uint32_t *eid0 = b.take<uint32_t>(n_ent), *eid1 = b.take<uint32_t>(n_ent), *eflag = b.take<uint32_t>(n_ent), *ent_rank = ds.ent_rank;
 
     if (n_rings) {
         memcpy(pin, rings.data(), n_rings * sizeof(RingEnt));
@@ -394,7 +404,7 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
     TRY_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(uint32_t), st));
     auto grid = [](uint64_t items, uint32_t block) { return dim3((uint32_t)std::max<uint64_t>(1, (items + block - 1) / block)); };
     // f1: plane fits
-    if (nr) hipLaunchKernelGGL(k_fit_planes, grid(nr, 128), dim3(128), 0, st, (uint32_t)nr, (const uint32_t *)ds.res_atom_ptr, (const uint32_t *)ds.res_atom_idx,
+    if (nr && derive) hipLaunchKernelGGL(k_fit_planes, grid(nr, 128), dim3(128), 0, st, (uint32_t)nr, (const uint32_t *)ds.res_atom_ptr, (const uint32_t *)ds.res_atom_idx,
                                (const uint8_t *)ds.plane_bits, (const double *)ds.x, (const double *)ds.y, (const double *)ds.z, ring_pl, sc_pl, valid);
     // atom-atom rows: bit count -> offsets -> rows (after the total is known)
     if (n_pairs) {
@@ -404,7 +414,7 @@ arp_status device_table(arp_context *ctx, const DevStructure &ds, const std::vec
         TRY_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, (const uint32_t *)bits, first, (int)n_pairs + 1, st));
     }
     // entity ranks: sort the entities by (resi, altloc, atomi), least significant key first; rank = number of key changes before
-    {
+    if (derive) {
         hipLaunchKernelGGL(k_iota, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, eid0);
         hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, 0,
                            (const uint32_t *)nullptr, ek0);
