@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <algorithm>
 #include <atomic>
@@ -517,7 +518,10 @@ arp_status arp::contacts_atomic_view(arp_context *ctx, const arp_atoms *atoms, c
         if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
         if ((s = upload_params(ctx, params)) != ARP_OK) return s;
         unsigned long long total = 0;
+        const bool timing = getenv("ARP_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         s = single_pass_into_context_buffer(ctx, atoms->n, d, params, ctx->prof.enabled ? &ctx->prof : nullptr, &total);
+        if (timing) fprintf(stderr, "    pair pass (launches + sync)      %8.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (s == kRetryDefer) { if ((s = grow_defer_list(ctx, atoms->n)) != ARP_OK) return s; continue; }
         if (s != ARP_OK) return s;
         *data = ctx->out_buf; *n = total;

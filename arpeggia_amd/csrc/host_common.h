@@ -3,6 +3,7 @@
 #include <array>
 #include <cstdarg>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -70,6 +71,7 @@ struct arp_structure {
     bool groups_valid = false;
     // table.cpp: derived per-structure tables of the table path + the device-resident copy (built on the first arp_get_contacts)
     void *table_cache = nullptr;
+    std::mutex table_cache_mu;   // guards the creation of table_cache
     void (*table_cache_free)(void *) = nullptr;
     ~arp_structure() { if (table_cache && table_cache_free) table_cache_free(table_cache); }
 };

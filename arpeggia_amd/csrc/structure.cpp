@@ -572,6 +572,7 @@ arp_status parse_groups(const std::vector<std::string> &all, const char *groups,
 }
 
 arp_status apply_groups(arp_structure *s, const char *groups) {
+    if (s->groups_valid && s->groups_applied == groups) return ARP_OK;  // the attribute words already carry this spec (a pass over every atom otherwise)
     std::vector<std::string> L, R;
     arp_status st = parse_groups(s->chain_ids, groups, &L, &R);
     if (st != ARP_OK) return st;

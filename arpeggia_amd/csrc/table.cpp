@@ -310,6 +310,9 @@ struct TableCache {
     std::vector<EntKey> ring_keys;
     std::vector<uint32_t> ring_model_rank;
     std::shared_ptr<EntityBook> book;
+    std::mutex mu;                            // held for the whole of a device-table call on this structure
+    std::string rings_groups; bool have_rings_dev = false;   // the ring entities as the device wants them, for this chain-group spec
+    std::vector<RingEnt> rings_dev;
     DevStructure dev;
     ~TableCache() { if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); } }
 };
@@ -317,7 +320,9 @@ void free_table_cache(void *p) { delete (TableCache *)p; }
 uint32_t be32(const char *p) { return ((uint32_t)(unsigned char)p[0] << 24) | ((uint32_t)(unsigned char)p[1] << 16) | ((uint32_t)(unsigned char)p[2] << 8) | (uint32_t)(unsigned char)p[3]; }
 uint32_t be32s(const std::string &v) { char b[4] = {0, 0, 0, 0}; memcpy(b, v.data(), std::min<size_t>(3, v.size())); return be32(b); }
 
+// (Calls on ONE structure are serialised: its cache and its resident device copy are per-structure state.  Different structures run in parallel.)
 TableCache *table_cache_of(arp_structure *s) {
+    std::lock_guard<std::mutex> guard(s->table_cache_mu);
     if (s->table_cache) return (TableCache *)s->table_cache;
     TableCache *c = new TableCache();
     const size_t n = s->n, nr = s->residues.size();
@@ -498,7 +503,7 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
     return ARP_OK;
 }
 
-arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *groups, const arp_atoms &view, double vdw_comp, double dist_cutoff, arp_table **out) {
+arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp, double dist_cutoff, arp_table **out) {
     const bool timing = getenv("ARP_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -507,29 +512,38 @@ arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *g
         fprintf(stderr, "  get_contacts %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    (void)view;
     TableCache *c = table_cache_of(s);
+    std::lock_guard<std::mutex> one_call_per_structure(c->mu);
+    {   // InteractionComplex::new (complex.rs:36-68): the ligand / receptor bits of this chain-group spec (a no-op when unchanged)
+        const arp_status sg = apply_groups(s, groups);
+        if (sg != ARP_OK) return sg;
+    }
     if (c->rings.empty()) { set_error("Error building ring positions"); return ARP_ERR_NO_RINGS; }  // complex.rs:50
     lap("entities (cached)");
     arp_status st = ensure_resident(ctx, s, c, groups);
     if (st != ARP_OK) return st;
     lap("resident copy");
-    // chain sets of this call (utils.rs:71-115): chains without atoms still belong to them
-    std::vector<char> chain_l(s->chain_ids.size(), 0), chain_r(s->chain_ids.size(), 0);
-    std::unordered_map<std::string, uint16_t> rank;
-    for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
-    {
-        std::vector<std::string> L, R;
-        if ((st = parse_groups(s->chain_ids, groups, &L, &R)) != ARP_OK) return st;
-        for (auto &ch : L) chain_l[rank[ch]] = 1;
-        for (auto &ch : R) chain_r[rank[ch]] = 1;
+    // chain sets of this call (utils.rs:71-115): chains without atoms still belong to them.  Kept per chain-group spec: on a structure
+    // with thousands of chains this bookkeeping costs more than the GPU pair pass.
+    if (!c->have_rings_dev || c->rings_groups != groups) {
+        std::vector<char> chain_l(s->chain_ids.size(), 0), chain_r(s->chain_ids.size(), 0);
+        std::unordered_map<std::string, uint16_t> rank;
+        for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
+        {
+            std::vector<std::string> L, R;
+            if ((st = parse_groups(s->chain_ids, groups, &L, &R)) != ARP_OK) return st;
+            for (auto &ch : L) chain_l[rank[ch]] = 1;
+            for (auto &ch : R) chain_r[rank[ch]] = 1;
+        }
+        c->rings_dev.resize(c->rings.size());
+        for (size_t k = 0; k < c->rings_dev.size(); k++) {
+            PlaneEntry &e = c->rings[k];
+            e.chain_rank = rank[e.chain]; e.in_l = chain_l[e.chain_rank]; e.in_r = chain_r[e.chain_rank];
+            c->rings_dev[k] = RingEnt{e.res, e.model_serial, c->ring_model_rank[k], e.chain_rank, (e.in_l ? 1u : 0u) | (e.in_r ? 2u : 0u) | (e.has_ord ? 4u : 0u), e.ord, c->ring_sc_src[k], 0u};
+        }
+        c->rings_groups = groups; c->have_rings_dev = true;
     }
-    std::vector<RingEnt> rings(c->rings.size());
-    for (size_t k = 0; k < rings.size(); k++) {
-        PlaneEntry &e = c->rings[k];
-        e.chain_rank = rank[e.chain]; e.in_l = chain_l[e.chain_rank]; e.in_r = chain_r[e.chain_rank];
-        rings[k] = RingEnt{e.res, e.model_serial, c->ring_model_rank[k], e.chain_rank, (e.in_l ? 1u : 0u) | (e.in_r ? 2u : 0u) | (e.has_ord ? 4u : 0u), e.ord, c->ring_sc_src[k], 0u};
-    }
+    const std::vector<RingEnt> &rings = c->rings_dev;
     // get_atomic_contacts (complex.rs:189-299): the GPU hot path, on the resident arrays, list left on the device
     arp_params prm;
     arp_default_params(&prm);
@@ -578,12 +592,12 @@ extern "C" arp_status arp_get_contacts_mt(arp_context *ctx, arp_structure *s, co
         fprintf(stderr, "  get_contacts %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
+    const bool host_table = getenv("ARP_TABLE_HOST") != nullptr;  // diagnostic: the round-1 host assembly (cross-check of the device table)
+    if (!host_table) return get_contacts_device(ctx, s, groups, vdw_comp, dist_cutoff, out);
     // InteractionComplex::new (complex.rs:36-68)
     arp_atoms view;
     arp_status st = arp_structure_atoms(s, groups, &view);
     if (st != ARP_OK) return st;
-    const bool host_table = getenv("ARP_TABLE_HOST") != nullptr;  // diagnostic: the round-1 host assembly (cross-check of the device table)
-    if (!host_table) return get_contacts_device(ctx, s, groups, view, vdw_comp, dist_cutoff, out);
     std::vector<PlaneEntry> rings, scp;
     PlaneIndex ring_idx, sc_idx;
     std::vector<int64_t> ring_first, sc_first;  // single-model structures: direct (residue, altloc) -> entry tables
