@@ -435,6 +435,17 @@ def test_packed_batch_reports_the_failing_structure(ctx):
         assert len(aa.atomic_contacts_batch([ctx], [structs[0].view("/"), structs[2].view("/")], prm)) == 2
 
 
+@pytest.mark.parametrize("kernel", ["gather", "lds", "blk"])
+def test_alternative_emit_kernels(kernel):
+    """The three other single-pass emit kernels (ARP_EMIT_KERNEL, read once per process) stay parity-green: each in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ARP_EMIT_KERNEL=kernel)
+    r = subprocess.run([sys.executable, str(synth.DATA.parent / "emit_kernel_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------------------------------------- BASELINE config 5: a batch of ~5k-atom structures
 def _config5_members(n_members, seed=5):
     """atoms ~ N(5000, 500^2) clipped to [3000, 7000], each structure built by S1 from the 1ubq template."""
