@@ -202,13 +202,15 @@ arp_status arp_structure_atoms(arp_structure *s, const char *groups, arp_atoms *
 const char *arp_structure_strings(const arp_structure *s, const char *column, int32_t *width);
 const int32_t *arp_structure_ints(const arp_structure *s, const char *column);
 
-/* Host worker threads of the table path (plane fits, row assembly, sort, columns): the reference's global rayon pool
- * (utils.rs:8-30; `num_threads` of python.rs:31).  1 = serial (default, as in the reference), 0 = all hardware threads.
- * The GPU search and classification do not depend on it. */
+/* Host worker threads of the table path (entity bookkeeping, copies out of pinned memory, column / Arrow materialisation -- the plane
+ * fits, ring rows, row assembly and sort run on the device): the reference's global rayon pool (utils.rs:8-30; `num_threads` of
+ * python.rs:31).  1 = serial (default, as in the reference), 0 = all hardware threads.  The table is identical for every count. */
 void arp_set_num_threads(int32_t n);
 int32_t arp_get_num_threads(void);
 
-/* ---- the table: replaces arpeggia::get_contacts (mod.rs:61-137) ---- */
+/* ---- the table: replaces arpeggia::get_contacts (mod.rs:61-137) ----
+ * The structure is kept resident on the context's device (uploaded once, with its fitted planes and entity ranks); calls on ONE
+ * arp_structure are serialised inside the library, different structures (on different contexts) run in parallel. */
 arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp,
                             double dist_cutoff, arp_table **out);
 /* The same with the host worker count of THIS call given explicitly (the reference sizes a scoped rayon pool per call,
