@@ -14,7 +14,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libarpeggia_amd.so"
 SOURCES = ["kernels.hip", "engine.cpp", "structure.cpp", "table.cpp", "table_dev.hip"]
-HEADERS = ["arp_internal.h", "host_common.h", "grid.inl", "pairs.inl", "pairs_lds.inl", "pairs_hyb.inl", "pairs_blk.inl", "batch.inl", "sap.inl", "table_dev.h", "../../include/arpeggia_amd.h"]
+HEADERS = ["arp_internal.h", "host_common.h", "grid.inl", "pairs.inl", "pairs_emit.inl", "batch.inl", "sap.inl", "table_dev.h", "../../include/arpeggia_amd.h"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-result",
          # the kernels aggregate their atomics by hand (one lane per wave / per run); the compiler's own wave aggregation only wraps
          # those single-lane atomics in dead mbcnt / readfirstlane / multiply sequences

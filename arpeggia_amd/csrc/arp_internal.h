@@ -27,7 +27,10 @@ struct DevParams {
 // Uniform grid, written by the device-side setup kernel (no host round trip).
 struct GridParams {
     double ox, oy, oz;    // origin = min corner of the heavy atoms
-    double inv_edge;      // 1 / cell edge, edge >= dist_cutoff * (1 + 1e-6)
+    double inv_edge;      // 1 / cell edge in y and z, edge >= dist_cutoff * (1 + 1e-6)
+    double inv_edge_x;    // kx / edge: cells are kx times finer along x (the fastest-running cell index), so that a lane's slot windows
+                          // -- x-runs of 2 kx + 1 cells -- hug the search sphere: the same five windows, up to a third fewer tests
+    uint32_t kx;          // x cells per cell edge (1, 2 or 4): a neighbour within the cutoff is at most kx cells away along x
     uint32_t nx, ny, nz;  // cells per axis for ONE model
     uint32_t nzt;         // total z layers = n_models * (nz + 1): each model gets its own slab + an empty separator
     uint32_t ncells;      // nx * ny * nzt
@@ -55,15 +58,17 @@ struct DevAtoms {
 
 // Exact-phase record of one heavy atom, 48 B = three 16-byte parts.  The hot kernels read parts 0 and 1 whole and the first
 // half of part 2; `attr` (the caller's word + the residue-has-hydrogens bit) is only read by the deferred probe passes.
-//   pw = pair word, built when the atom is placed (grid.inl make_pair_word): element class in bits 0-3, the class bits the
+//   pw = pair word, built when the atom is placed (grid.inl make_pair_word): element class in bits 0-3 and again in bits 4-7, the class bits the
 //   pair rules combine as two bytes P (bits 8-14) and Q (bits 16-22) such that (Pa & Qb) | (Pb & Qa) has one bit per pair
-//   predicate, LIGAND / RECEPTOR in bits 24 / 25, residue-has-hydrogens in bit 31.
+//   predicate, LIGAND / RECEPTOR in bits 24 / 25, residue-has-hydrogens in bit 30.
+//   {res_ord, crm} sit side by side: read as one 64-bit word they are the key (model, chain rank, residue ordinal) that orders the two atoms
+//   of a pair when every atom is in both chain sets (orient_all_both).
 struct __attribute__((aligned(16))) Fat {
     double x, y;
-    double z; uint32_t pw, res_ord;
-    uint32_t crm /* chain_rank | model << 16 */, orig /* index into the caller's arrays */, cell /* cell id of the slot */, attr;
+    double z; uint32_t pw, orig /* index into the caller's arrays */;
+    uint32_t res_ord, crm /* chain_rank | model << 16 */, cell /* cell id of the slot */, attr;
 };
-constexpr uint32_t kPwLigand = 1u << 24, kPwReceptor = 1u << 25, kPwResHasH = 1u << 31;
+constexpr uint32_t kPwLigand = 1u << 24, kPwReceptor = 1u << 25, kPwResHasH = 1u << 30;  // (bits 26-29 and 31 stay clear: the emit kernel ANDs the word with a table entry's probe bits)
 
 // Cell-sorted copy of the heavy atoms (slot order: x-major cells, atoms of a cell in ascending input index).
 struct Sorted {
@@ -135,7 +140,8 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
 void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out, bool contacts_only);
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof,
                          bool contacts_only);
-void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only);
+void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+                 bool skip_deferred);
 unsigned long long emit_scratch_records();
 void launch_neighbor_sum(const DevAtoms &in, const Workspace &ws, double radius, double r2, const float *weight, float *out, hipStream_t st);
 void launch_pack_fix(const PackArrays &pa, hipStream_t st);

@@ -110,7 +110,13 @@ struct arp_context {
     unsigned long long *h_offsets = nullptr;  // pinned: per-member offsets into the grouped list (+ the pack status word)
     uint64_t h_offsets_cap = 0;
     DevParams *h_params = nullptr;         // pinned
-    unsigned long long *h_result = nullptr;  // pinned [2]
+    unsigned long long *h_result = nullptr;  // pinned [4]: pairs, status flags, emit allocator head, deferred-list chunks
+    // Deferred-pass memo: the arrays (address + length) of the last single-pass call that deferred NOTHING to the probe pass (no hydrogens,
+    // no CYS SG pair in the covalent band -- every X-ray structure without hydrogens).  The next call on the same arrays does not launch
+    // k_pairs_deferred; should it defer after all (the caller rewrote the arrays), k_fixup raises status bit 128 and the call is repeated
+    // with the pass.  A guess that is checked on the device, never a correctness assumption.
+    const double *nodefer_x = nullptr; uint64_t nodefer_n = 0;
+    bool last_skip = false;
     arp_params last_params{};
     bool have_params = false;
     uint64_t last_capacity = 0;
@@ -162,7 +168,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.perm, cap); A(w.slot_cell, cap);
     A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
-    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 32);  // result[8..31]: cycle stamps of diagnostic builds (ARP_STAMP)  // scan_tmp*: >= kScanBlocks + 1
+    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 32);  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
     A(w.model_box, 65536u * 6u); A(w.model_org, 65536u * 6u);
     w.defer_cap = (uint64_t)ctx->defer_scale * std::max<uint64_t>(16 * cap, 1u << 20) + (1u << 20);  // + one partly used 512-entry chunk per block
@@ -200,7 +206,7 @@ extern "C" arp_status arp_context_create(int32_t device, arp_context **out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_params, sizeof(DevParams), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 4 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) {
         set_error("HIP error %d (%s) creating the context", (int)e, hipGetErrorString(e));
         arp_context_destroy(ctx);
@@ -317,8 +323,17 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
     return ARP_OK;
 }
 
-constexpr arp_status kRetryDefer = -1;  // internal: never crosses the C ABI
+constexpr arp_status kRetryDefer = -1;      // internal: never crosses the C ABI
+constexpr arp_status kRetryDeferPass = -2;  // internal: the deferred pass was skipped on a memo that no longer holds
+static bool skip_deferred_pass(arp_context *ctx, const DevAtoms &d) { return d.x != nullptr && ctx->nodefer_x == d.x && ctx->nodefer_n == d.n; }
+// after the results of a single-pass (emit) call have been read into h_result
+static void note_deferred(arp_context *ctx, const DevAtoms &d, bool skipped) {
+    if (skipped) { if (ctx->h_result[1] & 128ull) { ctx->nodefer_x = nullptr; ctx->nodefer_n = 0; } return; }
+    if (ctx->h_result[3] == 0ull && !(ctx->h_result[1] & ~1ull)) { ctx->nodefer_x = d.x; ctx->nodefer_n = d.n; }
+    else if (ctx->nodefer_x == d.x) { ctx->nodefer_x = nullptr; ctx->nodefer_n = 0; }
+}
 static arp_status flags_to_status(unsigned long long flags) {
+    if (flags & 128ull) return kRetryDeferPass;
     if (flags & 4ull) { set_error("non-finite atom coordinate"); return ARP_ERR_BAD_INPUT; }
     if (flags & 64ull) { set_error("model ordinals must be dense: the largest model id exceeds what the workspace of this input holds (model ids count 0, 1, 2, ...)"); return ARP_ERR_BAD_INPUT; }
     if (flags & 16ull) { set_error("internal error: inconsistent hole plan in k_fixup"); return ARP_ERR_HIP; }
@@ -430,10 +445,11 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
         launch_count(d, ctx->ws, ctx->stream, prof, capacity, true, only);
         launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof, only);
     } else {
-        launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only);
+        ctx->last_skip = skip_deferred_pass(ctx, d);
+        launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only, ctx->last_skip);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     ctx->last_capacity = capacity;
     ctx->last_atoms = *atoms; ctx->last_out = out;  // (device pointers: the caller keeps them alive until arp_contacts_atomic_result)
     ctx->pending = true;
@@ -447,21 +463,17 @@ extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_p
     for (;;) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->pending = false;
-#ifdef ARP_STAMP   // diagnostic build: per-segment wave cycles of the emit kernel (summed over waves), see pairs_lds.inl
-        if (getenv("ARP_STAMP_PRINT")) {
-            unsigned long long st[24];
-            if (hipMemcpy(st, ctx->ws.result + 8, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
-                static const char *nm[] = {"total", "prologue", "stage", "prefilter", "compact", "exact_full", "exact_part", "handout", "n_full", "n_part", "n_chunks", "n_tasks"};
-                for (int k = 0; k < 12; k++) fprintf(stderr, "stamp %-10s %14llu%s", nm[k], st[k], k % 4 == 3 ? "\n" : "  ");
-            }
-        }
-#endif
         if (n_pairs) *n_pairs = ctx->h_result[0];
-        if ((s = flags_to_status(ctx->h_result[1])) != kRetryDefer) break;
-        // grow the deferred-probe list and run the enqueued call again (same inputs, same output buffer)
         const arp_atoms again = ctx->last_atoms;
         const arp_params prm = ctx->last_params;
-        if ((s = grow_defer_list(ctx, again.n)) != ARP_OK) return s;
+        if (ctx->last_out && ctx->last_capacity && !(prm.flags & ARP_FLAG_DETERMINISTIC)) {  // a single-pass call: keep the deferred-pass memo
+            DevAtoms d{}; d.x = again.x; d.n = (uint32_t)again.n;
+            note_deferred(ctx, d, ctx->last_skip);
+        }
+        s = flags_to_status(ctx->h_result[1]);
+        if (s != kRetryDefer && s != kRetryDeferPass) break;
+        // grow the deferred-probe list (or: run the probe pass after all) and run the enqueued call again (same inputs, same output buffer)
+        if (s == kRetryDefer && (s = grow_defer_list(ctx, again.n)) != ARP_OK) return s;
         if ((s = arp_contacts_atomic_enqueue(ctx, &again, &prm, ctx->last_out, ctx->last_capacity)) != ARP_OK) return s;
     }
     if (s != ARP_OK) return s;
@@ -490,11 +502,14 @@ static arp_status single_pass_into_context_buffer(arp_context *ctx, uint64_t n_a
             ctx->out_cap = want;
         }
         launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false); ctx->grid_x = d.x; ctx->grid_n = d.n;
-        launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0);
+        const bool skip = skip_deferred_pass(ctx, d);
+        launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0, skip);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
+        note_deferred(ctx, d, skip);
+        if ((s = flags_to_status(ctx->h_result[1])) == kRetryDeferPass) { attempt--; continue; }  // the memo was stale: once more, with the probe pass
+        if (s != ARP_OK) return s;
         total = ctx->h_result[0];
         if (total <= ctx->out_cap) break;
         if (attempt) { set_error("internal error: pair count changed between passes"); return ARP_ERR_HIP; }
@@ -565,7 +580,7 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
     launch_count(d, ctx->ws, ctx->stream, prof, 0, false, only && ordered);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
     unsigned long long total = ctx->h_result[0];
@@ -573,9 +588,9 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     arp_pair *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
     if (params->flags & ARP_FLAG_DETERMINISTIC) launch_fill_ordered(d, ctx->ws, dev, total, ctx->stream, prof, only);
-    else launch_emit(d, ctx->ws, dev, total, ctx->stream, prof, only);
+    else launch_emit(d, ctx->ws, dev, total, ctx->stream, prof, only, false);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(dev); set_error("HIP error %d (%s) in the fill pass", (int)e, hipGetErrorString(e)); return ARP_ERR_HIP; }
     if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) { (void)hipFree(dev); return s; }
@@ -706,11 +721,11 @@ arp_status enqueue_pack_kernels(BatchSlot &sl, const arp_params *params) {
         launch_count(sl.dev, ctx->ws, ctx->stream, prof, ctx->out_cap, true, only);
         launch_fill_ordered(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only);
     } else {
-        launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only);
+        launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only, false);
     }
     launch_pack_split(sl.pa, ctx->ws.result, ctx->out_buf, ctx->grp_buf, sl.ordered, ctx->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_offsets, sl.pa.offset, (sl.pa.K + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_offsets + sl.pa.K + 1, sl.pa.status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     return ARP_OK;
@@ -971,7 +986,7 @@ extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const d
     HIP_TRY(hipGetLastError());
     float *h_out = (float *)(pin + ((n * 4 + 255u) & ~255ull));
     HIP_TRY(hipMemcpyAsync(h_out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->ws.grid) {  // non-finite coordinates are reported by the grid build through the fix-up kernel only; check here
         for (uint64_t i = 0; i < n; i++)

@@ -26,15 +26,24 @@ DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, 
     // reference only ever uses cutoff^2, complex.rs:191, so a negative cutoff searches the same sphere)
     double edge = fabs(cutoff) * (1.0 + 1e-6);
     if (!(edge > 1e-3)) edge = 1e-3;
+    // cells kx = 4, 2 or 1 times finer along x, as the cell budget allows (arp_internal.h GridParams::kx)
     double nx, ny, nz;
+    uint32_t kx = 4u;
     for (int it = 0;; ++it) {
-        nx = floor(ext[0] / edge) + 1.0; ny = floor(ext[1] / edge) + 1.0; nz = floor(ext[2] / edge) + 1.0;
+        ny = floor(ext[1] / edge) + 1.0; nz = floor(ext[2] / edge) + 1.0;
+        for (kx = 4u; kx > 1u; kx >>= 1) {
+            nx = floor(ext[0] * (double)kx / edge) + 1.0;
+            if (nx * ny * (nz + 1.0) * (double)nm <= (double)ncells_cap) break;
+        }
+        nx = floor(ext[0] * (double)kx / edge) + 1.0;
         if (nx * ny * (nz + 1.0) * (double)nm <= (double)ncells_cap) break;
-        if (it >= 512) { nx = ny = nz = 1.0; edge = INFINITY; break; }  // unreachable for finite extents (1.26^512 overflows first); a bound, not a hope
+        if (it >= 512) { nx = ny = nz = 1.0; kx = 1u; edge = INFINITY; break; }  // unreachable for finite extents (1.26^512 overflows first); a bound, not a hope
         edge *= 1.2599210498948732;  // sparse / huge extents: coarser cells stay correct (edge >= cutoff)
     }
     g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2];
     g->inv_edge = isfinite(edge) ? 1.0 / edge : 0.0;
+    g->inv_edge_x = isfinite(edge) ? (double)kx / edge : 0.0;
+    g->kx = kx;
     g->nx = (uint32_t)nx; g->ny = (uint32_t)ny; g->nz = (uint32_t)nz;
     g->nzt = nm * (g->nz + 1u);
     g->ncells = g->nx * g->ny * g->nzt;
@@ -57,18 +66,6 @@ DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, 
 // Bounding box in two launches: per-block partial results with plain stores, then one block reduces them and sizes the grid.
 // (A single launch with an arrival ticket was measured 2-3x slower: the per-block device-scope atomics / write-through
 // stores cost more than the extra launch.)  partials: [kBoundsBlocks][8] doubles = {min xyz, max xyz, models, bad}.
-// Loads of the caller's arrays, each read once per pass.  ARP_NT_LOAD (diagnostic builds): non-temporal.
-#ifndef ARP_NT_LOAD
-#define ARP_NT_LOAD 0
-#endif
-#ifndef ARP_NT_PLACE
-#define ARP_NT_PLACE 0
-#endif
-#if ARP_NT_LOAD
-#define ARP_LD(p) __builtin_nontemporal_load(&(p))
-#else
-#define ARP_LD(p) (p)
-#endif
 struct BoxAcc {
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t models = 0, bad = 0;
@@ -110,8 +107,8 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = min(i0 + (uint32_t)u * stride, last);
-            at[u] = ARP_LD(in.attr[i]); md[u] = (uint32_t)ARP_LD(in.model[i]);
-            p[u][0] = ARP_LD(in.x[i]); p[u][1] = ARP_LD(in.y[i]); p[u][2] = ARP_LD(in.z[i]);
+            at[u] = in.attr[i]; md[u] = (uint32_t)in.model[i];
+            p[u][0] = in.x[i]; p[u][1] = in.y[i]; p[u][2] = in.z[i];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -166,7 +163,7 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
     __shared__ double s_mn[4][3], s_mx[4][3];
     __shared__ uint32_t s_models[4], s_bad[4];
     for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
-    if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results, [8..31] cycle stamps of diagnostic builds
+    if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results
     BoxAcc acc;
     for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {
         const double *p = partials + 8 * b;
@@ -227,7 +224,7 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
 DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
     double ox = g.ox, oy = g.oy, oz = g.oz;
     if (g.model_org) { const double *o = g.model_org + 6u * model; ox = o[0]; oy = o[1]; oz = o[2]; }  // packed batch: the member's own corner
-    double fx = (x - ox) * g.inv_edge, fy = (y - oy) * g.inv_edge, fz = (z - oz) * g.inv_edge;
+    double fx = (x - ox) * g.inv_edge_x, fy = (y - oy) * g.inv_edge, fz = (z - oz) * g.inv_edge;
     uint32_t cx = (fx >= 0.0) ? (uint32_t)fmin(fx, 4.0e9) : 0u;  // NaN -> 0
     uint32_t cy = (fy >= 0.0) ? (uint32_t)fmin(fy, 4.0e9) : 0u;
     uint32_t cz = (fz >= 0.0) ? (uint32_t)fmin(fz, 4.0e9) : 0u;
@@ -253,8 +250,8 @@ __global__ __launch_bounds__(kCidThreads) void k_cellid(DevAtoms in, const GridP
 #pragma unroll
     for (uint32_t u = 0; u < kCidPer; u++) {  // unconditional loads from a clamped index: all of them in flight together
         const uint32_t i = min(i0 + u * kCidThreads, last);
-        at[u] = ARP_LD(in.attr[i]); md[u] = (uint32_t)ARP_LD(in.model[i]);
-        p[u][0] = ARP_LD(in.x[i]); p[u][1] = ARP_LD(in.y[i]); p[u][2] = ARP_LD(in.z[i]);
+        at[u] = in.attr[i]; md[u] = (uint32_t)in.model[i];
+        p[u][0] = in.x[i]; p[u][1] = in.y[i]; p[u][2] = in.z[i];
     }
     __syncthreads();
     uint32_t c[kCidPer], slot[kCidPer], r[kCidPer];
@@ -384,22 +381,17 @@ DEVFN uint32_t make_pair_word(uint32_t attr, bool res_has_h) {
                    hyd = (attr >> 9) & 1u, sg = (attr >> 10) & 1u;
     const uint32_t P = don | (wdon << 1) | (pos << 2) | (pos << 3) | (neg << 4) | (hyd << 5) | (sg << 6);
     const uint32_t Q = acc | (acc << 1) | (neg << 2) | (pos << 3) | (neg << 4) | (hyd << 5) | (sg << 6);
-    return (attr & ARP_ATTR_ELEM_MASK) | (P << 8) | (Q << 16) | ((attr & ARP_ATTR_LIGAND) ? kPwLigand : 0u) | ((attr & ARP_ATTR_RECEPTOR) ? kPwReceptor : 0u) |
+    return (attr & ARP_ATTR_ELEM_MASK) | ((attr & ARP_ATTR_ELEM_MASK) << 4) | (P << 8) | (Q << 16) | ((attr & ARP_ATTR_LIGAND) ? kPwLigand : 0u) | ((attr & ARP_ATTR_RECEPTOR) ? kPwReceptor : 0u) |
            (res_has_h ? kPwResHasH : 0u);
 }
 
 DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so, uint32_t i, uint32_t c, uint32_t d) {
-    const double x = ARP_LD(in.x[i]), y = ARP_LD(in.y[i]), z = ARP_LD(in.z[i]);
+    const double x = in.x[i], y = in.y[i], z = in.z[i];
     double mx = gp->mx, my = gp->my, mz = gp->mz;
     if (gp->model_org) { const double *o = gp->model_org + 6u * (uint32_t)in.model[i] + 3u; mx = o[0]; my = o[1]; mz = o[2]; }
     const float fx = (float)(x - mx), fy = (float)(y - my), fz = (float)(z - mz);
     const float4 rv = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
-#if ARP_NT_PLACE   // diagnostic: the sorted copies streamed past the L2 as well
-    { typedef float pl_f32x4 __attribute__((ext_vector_type(4))); const pl_f32x4 v = {rv.x, rv.y, rv.z, rv.w};
-      __builtin_nontemporal_store(v, reinterpret_cast<pl_f32x4 *>(so.rec + d)); }
-#else
     so.rec[d] = rv;
-#endif
     // "the residue carries hydrogens" as a bit of the record: the hot kernel never touches the hydrogen tables, the deferred
     // pass resolves residue -> hydrogens itself (hbond.rs:38-42)
     bool has_h = false;
@@ -407,20 +399,13 @@ DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so
         const uint32_t r = in.res_id[i];
         has_h = in.res_h_ptr[r] < in.res_h_ptr[r + 1];
     }
-    const uint32_t attr = ARP_LD(in.attr[i]) & ~kAttrResHasH;
+    const uint32_t attr = in.attr[i] & ~kAttrResHasH;
     Fat f;
     f.x = x; f.y = y; f.z = z;
-    f.pw = make_pair_word(attr, has_h); f.res_ord = ARP_LD(in.res_ord[i]);
-    f.crm = (uint32_t)ARP_LD(in.chain_rank[i]) | ((uint32_t)ARP_LD(in.model[i]) << 16); f.orig = i; f.cell = c;
+    f.pw = make_pair_word(attr, has_h); f.res_ord = in.res_ord[i];
+    f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i; f.cell = c;
     f.attr = attr | (has_h ? kAttrResHasH : 0u);
-#if ARP_NT_PLACE
-    { typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
-      pl_u32x4 q[3]; __builtin_memcpy(q, &f, 48);
-      pl_u32x4 *dst = reinterpret_cast<pl_u32x4 *>(so.fat + d);
-      __builtin_nontemporal_store(q[0], dst); __builtin_nontemporal_store(q[1], dst + 1); __builtin_nontemporal_store(q[2], dst + 2); }
-#else
     so.fat[d] = f;
-#endif
 }
 
 // Emit mode: slot = cell_start + arrival rank.  Reads are coalesced (input order), each atom writes its 72 bytes once.

@@ -2,7 +2,7 @@
 //
 // Pipeline (all on one stream, no host round trip):
 //   k_bounds (+ grid setup) -> k_cellid -> scan(cell_count) -> k_place | k_scatter + k_gather          (grid.inl)
-//   -> k_pairs<emit> -> k_pairs_deferred -> k_fixup   |   k_pairs<count> -> scan -> k_pairs<fill>    (pairs.inl)
+//   -> k_emit -> k_pairs_deferred -> k_fixup   |   k_pairs<count> -> scan -> k_pairs<fill>    (pairs_emit.inl, pairs.inl)
 // It replaces the reference's R*-tree build + serial neighbour walk + rayon classification
 // (src/contacts/complex.rs:189-299) with a uniform-grid cell list and a count/scan/fill pair emitter whose
 // output order is deterministic.  Decisions are made in f64 with the reference's operation order and no FMA
@@ -232,7 +232,7 @@ DEVFN uint32_t classify_fast(const LdsParams &prm, double s, uint32_t pa, uint32
     const uint32_t L = (s < prm.s_hphob ? 1u : 0u) + (s < prm.s_ion ? 1u : 0u) + (s < prm.s_polar ? 1u : 0u);  // d <= 4.5 / 4.0 / 3.5
     const uint32_t W = (((pa >> 8) & (pb >> 16)) | ((pb >> 8) & (pa >> 16))) & 0x7Fu;
     const uint32_t t = prm.lut[W | (L << 7)];
-    const uint32_t probe = ((t >> 30) & ((pa | pb) >> 31)) | ((cov ? 1u : 0u) & (t >> 29) & have_res);
+    const uint32_t probe = ((t & (pa | pb)) >> 30) | ((cov ? 1u : 0u) & (t >> 29) & have_res);  // (kPwResHasH = bit 30, like the table's flag)
     uint32_t kind = (t & 0x1FFFFFFFu) | (cov ? (1u << ARP_CovalentBond) : (vdw ? (1u << ARP_VanDerWaalsContact) : 0u));
     kind = (probe & 1u) ? kDeferKind : kind;
     return clash ? (1u << ARP_StericClash) : kind;                                               // complex.rs:233-235
@@ -260,9 +260,7 @@ DEVFN float dist_f32(double s) {
 
 // ---------------------------------------------------------------------------------------------- pair search + launch
 #include "pairs.inl"
-#include "pairs_lds.inl"
-#include "pairs_hyb.inl"
-#include "pairs_blk.inl"
+#include "pairs_emit.inl"
 #include "batch.inl"
 #include "sap.inl"
 

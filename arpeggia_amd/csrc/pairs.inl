@@ -1,8 +1,9 @@
 // Pair search, classification and emission kernels + the launch sequence.  Included by kernels.hip inside namespace arp.
 //
 // One wave-task = 64 consecutive slots of the cell-sorted order; lane = home atom (kept in registers).
-// Half shell: the rest of the home cell and its +x neighbour, the three cells of row (y+1, z) and the nine cells of
-// layer z+1 -- five contiguous slot windows per lane because cells are x-major.  Every unordered pair is tested
+// Half shell: the rest of the home cell and its kx neighbours towards +x, the 2 kx + 1 cells of row (y+1, z) around the home
+// column and the three such runs of layer z+1 -- five contiguous slot windows per lane because cells are x-major (and kx
+// times finer along x than the cutoff, GridParams::kx).  Every unordered pair is tested
 // exactly once; the reference's ordered pair (x in L, y in R) is recovered by candidate(), of which at most one
 // orientation can hold (complex.rs:108-130).
 //
@@ -22,31 +23,19 @@
 enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2, kCountContacts = 3 };
 //   kCountContacts  kCountTasks for ARP_FLAG_CONTACTS_ONLY: classifies, counts only the pairs with an interaction
 
-#ifndef ARP_WPB
-#define ARP_WPB 8
-#endif
-constexpr int kWavesPerBlock = ARP_WPB;   // (diagnostic builds: 7-wave blocks for 7 waves per SIMD)
+constexpr int kWavesPerBlock = 8;
 constexpr int kQueue = 128;
-#ifndef ARP_CHUNK
-#define ARP_CHUNK 256
-#endif
-constexpr uint32_t kChunk = ARP_CHUNK;      // neighbour records per staged chunk (4 KB)
+constexpr uint32_t kChunk = 256;            // neighbour records per staged chunk (4 KB)
 constexpr uint32_t kBlock = 16;             // prefilter tests per lane between two compaction steps
 constexpr uint32_t kReadAhead = 4;         // LDS reads in flight per lane in the prefilter (more costs a wave of occupancy in registers)
 constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each owning a contiguous range of wave-tasks
-#ifndef ARP_EMIT_WPS
-#define ARP_EMIT_WPS 6
-#endif
-constexpr int kEmitWavesPerSimd = ARP_EMIT_WPS;   // register budget of the emit kernel: 80 VGPRs at 6, 64 at 8
-constexpr uint32_t kEmitBlocks = (1024u * ARP_EMIT_WPS) / ARP_WPB;  // emit mode: blocks of 8 waves, ARP_EMIT_WPS waves per SIMD
+constexpr int kEmitWavesPerSimd = 6;       // register budget of the emit kernel: 80 VGPRs at 6, 64 at 8
+constexpr uint32_t kEmitBlocks = (1024u * kEmitWavesPerSimd) / kWavesPerBlock;  // emit mode: blocks of 8 waves, 6 waves per SIMD
 constexpr uint32_t kGrab = 1;              // wave-tasks drawn per atomic
-#ifndef ARP_CHUNK_RECORDS
-#define ARP_CHUNK_RECORDS 4096
-#endif
 // records per global allocation (one device atomic each).  The wave whose allocation crosses the end of the block's chunk fetches the
 // next one while the block's other waves sleep: 2048 -> 4096 halves those stalls (emit 221 -> 208 us); 8192 gains 2 us more and costs
 // the fix-up 8 us (holes grow with the chunk).
-constexpr uint32_t kChunkRecords = ARP_CHUNK_RECORDS;
+constexpr uint32_t kChunkRecords = 4096;
 
 template <int MODE>
 struct WaveLds {                                  // per-wave LDS working set
@@ -98,18 +87,11 @@ struct EmitTarget {  // positions >= capacity spill into the engine's scratch so
 };
 // Record stores are non-temporal: streamed past the L2 instead of left dirty in it.  The list is write-once and 16 B x P (460 MB on
 // the headline input); kept in the L2 it evicts the sorted records the gathers want and its write-back lands on whatever runs next
-// (measured: emit 244 -> 222 us, the following grid build 113 -> 88 us).  ARP_NT_STORE=0 builds the plain stores for comparison.
-#ifndef ARP_NT_STORE
-#define ARP_NT_STORE 1
-#endif
+// (measured: emit 244 -> 222 us, the following grid build 113 -> 88 us).
 typedef uint32_t rec_u32x4 __attribute__((ext_vector_type(4)));
 DEVFN void store_record(uint4 *p, const uint4 &r) {
-#if ARP_NT_STORE
     const rec_u32x4 v = {r.x, r.y, r.z, r.w};
     __builtin_nontemporal_store(v, reinterpret_cast<rec_u32x4 *>(p));
-#else
-    *p = r;
-#endif
 }
 DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned long long *result) {
     if (pos < tg.capacity) return reinterpret_cast<uint4 *>(tg.out) + pos;
@@ -185,49 +167,26 @@ DEVFN void load_lds_params(LdsParams &prm, const DevParams *dprm, const GridPara
 template <int MODE, bool PROBES>
 DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sorted &so, WaveLds<MODE> &w, BlockLds &bl, uint2 ent, bool active,
                              unsigned long long base, uint32_t emitted, const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags) {
-#if defined(ARP_ABLATE) && (ARP_ABLATE == 1 || ARP_ABLATE == 9)   // timing ablations: no exact phase at all (results are wrong by construction)
-    return (uint32_t)__popcll(__ballot(active));
-#endif
     bool valid = false, swap = false;
     double s = 0.0;
     Fat a, b;
     const bool all_both = !PROBES && (wflags & kWaveAllBoth);  // wave-uniform (held in a scalar register): a scalar branch, no divergence
     if (active) {
-#if defined(ARP_ABLATE) && ARP_ABLATE == 16   // timing ablation: the home operand read in lane order (coalesced, L1-resident): what would a cheap a-side buy?
-        a = fat_at<PROBES>(so.fat, (ent.x & ~63u) + lane); b = fat_at<PROBES>(so.fat, ent.y);
-#elif defined(ARP_ABLATE) && ARP_ABLATE == 17 // ... and both operands
-        a = fat_at<PROBES>(so.fat, (ent.x & ~63u) + lane); b = fat_at<PROBES>(so.fat, (ent.y & ~63u) + lane);
-#else
         a = fat_at<PROBES>(so.fat, ent.x); b = fat_at<PROBES>(so.fat, ent.y);  // the probe variants keep 64-bit addressing (inputs of any size)
-#endif
         s = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
         const int o = all_both ? orient_all_both(a, b) : orient(a, b);
         valid = (s <= prm.r2) & (o != 0);  // rstar: inclusive
         swap = o == 2;
-#if defined(ARP_ABLATE) && (ARP_ABLATE == 16 || ARP_ABLATE == 17)
-        valid = (s != 12345.678) | (o == 77); swap = false;  // every survivor goes on (the operands are the wrong ones): same amount of work downstream
-#endif
     }
     unsigned long long vm = __ballot(valid);
     const uint32_t nvalid = (uint32_t)__popcll(vm);
-#if defined(ARP_ABLATE) && ARP_ABLATE == 2   // timing ablation: loads + exact test + orientation, nothing after
-    if (MODE == kEmit) { if (valid && s == 12345.678) atomicOr(&result[1], 32ull); return nvalid; }
-#endif
     if (MODE != kCountTasks) {
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (valid) {
-#if defined(ARP_ABLATE) && ARP_ABLATE == 13   // timing ablation: no classification
-            r.w = (a.pw ^ b.pw) & 1u;
-#else
             if (PROBES) r.w = classify<true>(in, prm, s, a, b, swap, result);
             else r.w = classify_fast(prm, s, a.pw, b.pw, in.n_res != 0u ? 1u : 0u);
-#endif
             r.x = swap ? b.orig : a.orig; r.y = swap ? a.orig : b.orig;
-#if defined(ARP_ABLATE) && ARP_ABLATE == 14   // timing ablation: no output distance
-            r.z = __float_as_uint((float)s);
-#else
             r.z = __float_as_uint(dist_f32(s));
-#endif
         }
         if (wflags & kWaveContactsOnly) {  // ARP_FLAG_CONTACTS_ONLY: candidates without any interaction are dropped (kDeferKind != 0 stays)
             valid = valid && r.w != 0u;
@@ -271,29 +230,16 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
                 }
             }
             const uint32_t n = (uint32_t)__popcll(vm);
-#if defined(ARP_ABLATE) && ARP_ABLATE == 12   // timing ablation: no allocation, no store
-            if (valid && r.w == 0xDEADBEEFu) atomicOr(&result[1], 32ull);
-            if (false) {
-#else
             if (n) {  // compacted, coalesced store of the batch's records straight from registers
-#endif
                 const Slots sl = alloc_chunked<kChunkRecords>(bl.alloc_state, &result[2], n, lane);
                 const uint32_t rank = mbcnt(vm);
                 if (sl.n0 == n && sl.pos0 + n <= tg.capacity) {
                     // the common case, decided on the scalar unit: one run inside the caller's buffer -> scalar base + 32-bit lane offset
                     uint4 *run = reinterpret_cast<uint4 *>(tg.out) + sl.pos0;
-#if defined(ARP_ABLATE) && ARP_ABLATE == 11
-                    if (valid && r.w == 0xDEADBEEFu) run[rank] = r;
-#else
                     if (valid) store_record(&run[rank], r);
-#endif
                 } else if (valid) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
                     uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
-#if defined(ARP_ABLATE) && ARP_ABLATE == 11   // timing ablation: allocation but no store
-                    if (d && r.w == 0xDEADBEEFu) *d = r;
-#else
                     if (d) store_record(d, r);
-#endif
                 }
             }
         }
@@ -337,7 +283,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
+    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
     const uint32_t wflags = (gp->all_both ? kWaveAllBoth : 0u) | ((dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u);
     const double r2m = gp->r2m;
     WaveLds<MODE> &w = wl[wave];
@@ -370,10 +316,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
             uint32_t c = so.fat[a].cell;
             cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
         }
-        const uint32_t xlo = cx ? cx - 1 : 0, xhi = min(cx + 1, nx - 1);
-#if defined(ARP_ABLATE) && ARP_ABLATE == 9   // timing ablation: task hand-out + home record only (the fixed cost of the launch)
-        if (home.x != 1.2345e30f) continue;
-#endif
+        const uint32_t xlo = cx > kx ? cx - kx : 0u, xhi = min(cx + kx, nx - 1);
         // all five slot windows of this lane up front: ten independent loads in flight instead of five round trips
         uint32_t wlo[5] = {0, 0, 0, 0, 0}, whi[5] = {0, 0, 0, 0, 0};
         if (have) {
@@ -409,15 +352,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
                 const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
                 if (!__any(len != 0u)) continue;
                 wave_lds_fence();  // previous chunk fully consumed
-#if defined(ARP_NT_STAGE)   // diagnostic: staging loads marked non-temporal
-                for (uint32_t p = cs + lane; p < ce; p += 64u) {
-                    typedef float st_f32x4 __attribute__((ext_vector_type(4)));
-                    const st_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const st_f32x4 *>(so.rec + p));
-                    w.nrec[p - cs] = make_float4(v.x, v.y, v.z, v.w);
-                }
-#else
                 for (uint32_t p = cs + lane; p < ce; p += 64u) w.nrec[p - cs] = so.rec[p];
-#endif
                 wave_lds_fence();
                 const uint32_t off = len ? j0 - cs : 0u;
 #pragma unroll 1
@@ -446,14 +381,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
 #pragma unroll
                         for (uint32_t u = 0; u < kReadAhead; ++u) push_pass(mask, acc[u], thr);
                     }
-#if defined(ARP_PAD)   // timing probe: ARP_PAD extra VALU instructions per block (is the kernel VALU-issue bound?)
-                    {
-                        float pa = home.x, pb = home.y;
-#pragma unroll
-                        for (int q = 0; q < ARP_PAD / 2; q++) asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(pa), "+v"(pb));
-                        if (pa == 1.2345f && pb == 5.4321f) mask ^= 1u;
-                    }
-#endif
                     const uint32_t rem = len > it0 ? len - it0 : 0u;  // tests past the window end read other atoms: drop them
                     if (rem < kBlock) mask &= ~((1u << (kBlock - rem)) - 1u);
                     // Compaction: one round per surviving test of the busiest lane; every round appends <= 64 entries
@@ -574,8 +501,10 @@ DEVFN unsigned long long scan1024_u64(unsigned long long v, unsigned long long *
     *total = tot;
     return before + inc - v;  // exclusive
 }
+// no_deferred_pass: the launcher skipped k_pairs_deferred because the previous call on the same arrays deferred nothing (engine.cpp,
+// "deferred-pass memo"); if this call did defer candidates after all, status bit 128 makes the host repeat it with the pass.
 __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_list, uint32_t n_holes, const GridParams *g, EmitTarget tg,
-                                                       unsigned long long *result) {
+                                                       unsigned long long *result, uint32_t no_deferred_pass) {
     __shared__ unsigned long long fstart[kMaxHoles], fpre[kMaxHoles + 1];  // hole parts below P, any order
     __shared__ unsigned long long tpre[kMaxHoles + 1];                     // valid stretch of each chunk of [P, R) ...
     __shared__ unsigned int tlen[kMaxHoles];                               // ... and its length
@@ -617,6 +546,7 @@ __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_li
         if (F != T) result[1] |= 16ull;  // internal consistency check of the plan
         if (g->bad & 1u) result[1] |= 4ull;
         if (g->bad & 2u) result[1] |= 64ull;
+        if (no_deferred_pass && result[3] != 0ull) result[1] |= 128ull;
     }
     if (P > tg.capacity || F != T) return;  // the caller's buffer cannot hold the table: report the size only
     for (unsigned long long m = (unsigned long long)blockIdx.x * kFixThreads + i; m < F; m += (unsigned long long)gridDim.x * kFixThreads) {
@@ -734,24 +664,32 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
     if (prof) prof->end(st);
 }
 
-void launch_emit_x(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
-void launch_emit_b(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
-void launch_emit_h(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof);
+// what follows either emit kernel: the deferred probe pass (unless the engine's memo says this input defers nothing) and the hole fix-up
+static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const EmitTarget &tg, uint32_t nb, hipStream_t st, Profiler *prof, bool skip_deferred) {
+    if (prof) prof->end(st);
+    if (!skip_deferred) {
+        if (prof) prof->begin("pairs_deferred", st);
+        hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result);
+        if (prof) prof->end(st);
+    }
+    if (prof) prof->begin("pairs_fixup", st);
+    hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, skip_deferred ? nb : nb + kDeferBlocks, (const GridParams *)ws.grid, tg,
+                       ws.result, skip_deferred ? 1u : 0u);
+    if (prof) prof->end(st);
+}
+void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool skip_deferred);
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
-void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only) {
-    if (in.n >= kBigSlots) {  // beyond the 32-bit record offsets of the single-pass kernel: count + ordered fill with inline probes
+void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+                 bool skip_deferred) {
+    if (in.n >= kBigSlots) {  // beyond the 32-bit record offsets of the single-pass kernels: count + ordered fill with inline probes
         launch_count(in, ws, st, prof, capacity, true, contacts_only);
         launch_fill_ordered(in, ws, out, capacity, st, prof, contacts_only);
         return;
     }
-    // Four single-pass emit kernels exist, all parity-green (profiles/r02_emit_kernels.txt; S2 10^6 atoms): the default k_pairs_h
-    // (pairs_hyb.inl: home operand of the exact phase in LDS, 199 us), this file's k_pairs (both operands gathered, 210 us;
-    // ARP_EMIT_KERNEL=gather, and the fallback beyond k_pairs_h's 2^26 slots), k_pairs_x (=lds: both operands in LDS, 297 us) and
-    // k_pairs_b (=blk: block-cooperative, 297 us).
-    static const char emit_kernel = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] ? e[0] : 'h'; }();
-    if (emit_kernel == 'l') { launch_emit_x(in, ws, out, capacity, st, prof); return; }
-    if (emit_kernel == 'b') { launch_emit_b(in, ws, out, capacity, st, prof); return; }
-    if (emit_kernel != 'g' && in.n < (1u << 26) - 64u) { launch_emit_h(in, ws, out, capacity, st, prof); return; }
+    // The default is k_emit (pairs_emit.inl).  This file's k_pairs<kEmit> -- both exact operands gathered, 8-byte queue entries -- is the
+    // one alternative kept: it takes the inputs beyond k_emit's 2^26 slots, and ARP_EMIT_KERNEL=gather selects it for the parity suite.
+    static const bool gather = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'g'; }();
+    if (!gather && in.n < (1u << 26) - 64u) { launch_emit_e(in, ws, out, capacity, st, prof, skip_deferred); return; }
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1600)
         const char *e = getenv("ARP_EMIT_BLOCKS");
@@ -763,11 +701,5 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     hipLaunchKernelGGL((k_pairs<kEmit, false>), dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
                        (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,
                        ws.task_ctr, ws.result);
-    if (prof) { prof->end(st); prof->begin("pairs_deferred", st); }
-    hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg,
-                       ws.hole_list + nb, ws.result);
-    if (prof) { prof->end(st); prof->begin("pairs_fixup", st); }
-    hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, nb + kDeferBlocks, (const GridParams *)ws.grid, tg,
-                       ws.result);
-    if (prof) prof->end(st);
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred);
 }

@@ -1,0 +1,402 @@
+// The single-pass emitter (default): search, classify and emit in one kernel.  Included by kernels.hip after pairs.inl, inside
+// namespace arp.  Replaces the reference's R*-tree walk + per-pair rules (src/contacts/complex.rs:189-299).
+//
+// Shape (as k_pairs, pairs.inl): task = 64 consecutive slots of the cell-sorted order, lane = home atom, five contiguous slot
+// windows per lane (half shell; cells are kx times finer along x so the windows hug the search sphere), neighbour records staged
+// through a wave-private LDS chunk, an f32 prefilter with a proven margin, survivors compacted into an LDS queue, exact f64
+// phase on full waves of 64 survivors.
+//
+// What round 2's counters said (profiles/r02_pmc_summary.txt): the vector ALU is the pipe that binds (91 M instructions per
+// launch on the headline input, two thirds of them in the exact phase, ~130 per batch of 64 survivors), the LDS pipe second
+// (half of its cycles in the exact phase's table reads).  So this kernel is an instruction diet around the same data flow:
+//   * the wave-uniform bounds (cutoff^2, 3.5 / 4.0 / 4.5 A) live in scalar registers, not in LDS;
+//   * all rows of a pair come out of ONE 2048-entry LDS table indexed by {seven pair predicates, distance level against the
+//     three fixed bounds, distance level against the element pair's three bounds} -- the levels are counted with
+//     v_cmp_lt_f64 + v_addc_co_u32 (two instructions per bound), nothing is selected or branched on per rule;
+//   * every lane computes every step (no exec-masked regions inside a batch: a masked region costs scalar bookkeeping and
+//     saves no issue slot), only the stores are predicated;
+//   * the chain key {res_ord, chain | model} of an atom is one aligned 64-bit word, so "which atom is the ligand" is one
+//     64-bit compare (complex.rs:108-130 for chain groups "/");
+//   * the prefilter runs in groups of 8 tests (lockstep granularity: a wave runs as long as its longest window) and
+//     compacts once per 32 tests.
+constexpr uint32_t kEChunk = 128;             // staged neighbour records per chunk
+constexpr int kEWaves = 12;                   // waves per block: two blocks per CU share the CU's LDS, 6 waves per SIMD
+constexpr uint32_t kEBlocks = 256u * 2u;
+constexpr int kEWavesPerSimd = (kEWaves * 2) / 4;
+constexpr uint32_t kESlotBits = 26;           // neighbour slot bits of a queue entry; the launcher routes larger inputs to k_pairs
+constexpr uint32_t kESlotMask = (1u << kESlotBits) - 1u;
+constexpr uint32_t kEGroup = 8;               // prefilter tests per lane between two "is any window still open" checks
+constexpr uint32_t kEAcc = 32;                // prefilter tests per lane between two compactions (one mask word)
+constexpr uint32_t kEQueue = 128;             // the queue fills to 63 + 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct WaveLdsE {
+    float4 nrec[kEChunk + kEGroup];           // f32 prefilter records of the staged chunk (+ kEGroup: over-reads stay in bounds)
+    u32x4 hxy[64]; u32x4 hzp[64];             // the task's home atoms: {x, y}, {z, pw, orig} as raw words ...
+    unsigned long long hkey[64];              // ... and the chain key crm << 32 | res_ord
+    uint32_t queue[kEQueue];                  // phase-1 survivors: home lane << 26 | neighbour slot
+};
+struct TablesE {                              // block-shared decision tables (14.3 KB)
+    double s_clash[256], s_cov[256], s_vdw[256];   // bounds of the element pair (vdw.rs:32-43), index = class a << 4 | class b
+    uint32_t lut[2048];                       // rows of a pair: index = W | Lg << 7 | Le << 9 (pair_lut2_entry)
+};
+
+// Table entry for the seven pair predicates W (Fat::pw, classify_fast), the level Lg against the fixed bounds {4.5, 4.0, 3.5} and the
+// level Le against the element pair's bounds {vdw, cov, clash} (both nested, so the level is a count).  Bits 0-18: the rows that need no
+// probe (complex.rs:217-296), bit 30: a hydrogen probe decides if either residue carries hydrogens (hbond.rs:37,81), bit 29: the
+// disulfide dihedral decides if residue tables were given (vdw.rs:46-53).  A steric clash ends the pair (complex.rs:233-235).
+DEVFN uint32_t pair_lut2_entry(uint32_t idx) {
+    const uint32_t le = idx >> 9, base = pair_lut_entry(idx & 0x1FFu);
+    if (le == 3u) return 1u << ARP_StericClash;
+    uint32_t k = base & 0x1FFFFFFFu;
+    k |= le == 2u ? (1u << ARP_CovalentBond) : (le == 1u ? (1u << ARP_VanDerWaalsContact) : 0u);
+    k |= base & (1u << 30);
+    k |= le == 2u ? (base & (1u << 29)) : 0u;
+    return k;
+}
+DEVFN void load_tables_e(TablesE &tb, const DevParams *dprm) {
+    const double *src = dprm->s_clash;
+    double *dst = tb.s_clash;
+    for (uint32_t k = threadIdx.x; k < 3u * 256u; k += blockDim.x) dst[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) tb.lut[k] = pair_lut2_entry(k);
+}
+
+// compact_round (pairs.inl) with 4-byte entries: every lane with a surviving test appends tag + (count of leading zeros of its mask) at
+// byte address qaddr + 4 * (its rank among those lanes) and clears that bit.  Returns the ballot of the lanes that appended.
+DEVFN unsigned long long compact_round_e(uint32_t &mask, uint32_t tag, uint32_t qaddr) {
+    unsigned long long m, save;
+    uint32_t t, lz, ent, bm;
+    asm volatile(
+        "v_cmp_ne_u32 vcc, 0, %[mask]\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_ffbh_u32 %[lz], %[mask]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[qaddr]\n\t"
+        "v_add_u32 %[ent], %[tag], %[lz]\n\t"
+        "v_lshrrev_b32 %[bm], %[lz], %[top]\n\t"
+        "s_mov_b64 %[m], vcc\n\t"
+        "s_and_saveexec_b64 %[save], vcc\n\t"
+        "ds_write_b32 %[t], %[ent]\n\t"
+        "v_xor_b32 %[mask], %[mask], %[bm]\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [mask] "+v"(mask), [t] "=&v"(t), [lz] "=&v"(lz), [ent] "=&v"(ent), [bm] "=&v"(bm), [m] "=&s"(m), [save] "=&s"(save)
+        : [tag] "v"(tag), [qaddr] "s"(qaddr), [top] "s"(0x80000000u)
+        : "vcc", "memory");
+    return m;
+}
+
+struct ConstsE { double r2, s_hphob, s_ion, s_polar; };  // wave-uniform: scalar registers
+
+DEVFN double words_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+
+// Lane predicates as 64-bit scalar masks.  Left to the compiler, a predicate that is combined, balloted and branched on goes through
+// v_cndmask 0/1 + v_cmp_ne round trips (two vector instructions and a hazard nop per use); as a scalar value it is combined on the
+// scalar unit and only meets the vector pipe again as the condition of a select or as the exec mask of a store.
+typedef unsigned long long lmask;
+#define ARP_LMASK_CMP(NAME, OP, TA, CA, TB, CB)                                                                  \
+    DEVFN lmask NAME(TA a, TB b) {                                                                               \
+        lmask m;                                                                                                 \
+        asm(OP " vcc, %1, %2\n\ts_mov_b64 %0, vcc" : "=s"(m) : CA(a), CB(b) : "vcc");                            \
+        return m;                                                                                                \
+    }
+ARP_LMASK_CMP(lm_ge_f64_sv, "v_cmp_ge_f64_e32", double, "s", double, "v")      // a (scalar) >= b
+ARP_LMASK_CMP(lm_lt_u32_sv, "v_cmp_lt_u32_e32", uint32_t, "s", uint32_t, "v")  // a (scalar) <  b
+ARP_LMASK_CMP(lm_gt_u32_sv, "v_cmp_gt_u32_e32", uint32_t, "s", uint32_t, "v")  // a (scalar) >  b
+ARP_LMASK_CMP(lm_ne_u32, "v_cmp_ne_u32_e32", uint32_t, "v", uint32_t, "v")
+ARP_LMASK_CMP(lm_lt_u64, "v_cmp_lt_u64_e32", unsigned long long, "v", unsigned long long, "v")
+#undef ARP_LMASK_CMP
+DEVFN uint32_t lm_select(lmask m, uint32_t if_set, uint32_t if_clear) {
+    uint32_t d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(m));
+    return d;
+}
+DEVFN bool lm_lane(lmask m, uint32_t lane) { return (m >> lane) & 1ull; }  // (rare paths only: a 64-bit vector shift)
+DEVFN uint32_t lm_rank(lmask m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+// one 16-byte non-temporal record store per lane of m: scalar base + 32-bit lane offset (store_record, pairs.inl)
+DEVFN void lm_store_records(lmask m, uint4 *base, uint32_t byte_off, const u32x4 &rec) {
+    lmask save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx4 %2, %3, %4 nt\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(m), "v"(byte_off), "v"(rec), "s"(base) : "memory");
+}
+
+// Phase 2 on queue entries [first, first + count), count <= 64 (FULL: count == 64): home operands out of LDS, neighbour operands gathered
+// (40 of the 48 bytes of the exact record).  Every lane computes everything -- the lanes beyond count on entry 0 (home lane 0, slot 0: in
+// bounds) -- and only the stores are predicated.
+template <bool FULL>
+DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, const Sorted &so, uint32_t first, uint32_t count, uint32_t slot0,
+                         const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
+    first = __builtin_amdgcn_readfirstlane(first); count = __builtin_amdgcn_readfirstlane(count);  // (wave-uniform by construction: say so)
+    wave_lds_fence();  // lanes read entries other lanes wrote
+    uint32_t e = w.queue[first + lane];
+    if (!FULL) e = lane < count ? e : 0u;
+    wave_lds_fence();
+    const lmask m_act = FULL ? ~0ull : ((1ull << (count & 63u)) - 1ull);  // (!FULL: count < 64)
+    const uint32_t hl = e >> kESlotBits, nb = e & kESlotMask;
+    uint32_t goff;  // 48 nb as two full-rate instructions (fat_at, pairs.inl)
+    asm("v_lshl_add_u32 %0, %1, 1, %1\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(goff) : "v"(nb));
+    const char *gp = reinterpret_cast<const char *>(so.fat) + (size_t)goff;
+    const u32x4 bxy = *reinterpret_cast<const u32x4 *>(gp), bzp = *reinterpret_cast<const u32x4 *>(gp + 16);
+    const unsigned long long kb = *reinterpret_cast<const unsigned long long *>(gp + 32);
+    const u32x4 axy = w.hxy[hl], azp = w.hzp[hl];
+    const unsigned long long ka = w.hkey[hl];
+    // pdbtbx Atom::distance before the sqrt, f64, the reference's operation order, no contraction
+    const double s = sq_dist(words_f64(axy.x, axy.y), words_f64(axy.z, axy.w), words_f64(azp.x, azp.y), words_f64(bxy.x, bxy.y), words_f64(bxy.z, bxy.w),
+                             words_f64(bzp.x, bzp.y));
+    const uint32_t pa = azp.z, pb = bzp.z;
+    // should_compare_entities for both orientations (complex.rs:76-131); at most one can hold
+    lmask m_ok, m_swap;
+    if (wflags & kWaveAllBoth) {  // (wave-uniform: a scalar branch)  every atom in both chain sets: the ligand is the atom with the smaller key
+        const uint32_t d1 = (uint32_t)kb - (uint32_t)ka + 1u;                   // residue ordinals of one chain: |difference| >= 2 (:113)
+        m_ok = lm_lt_u32_sv(2u, d1) | lm_ne_u32((uint32_t)(ka >> 32), (uint32_t)(kb >> 32));  // another chain: always (:124-129); models never meet in the grid
+        m_swap = lm_lt_u64(kb, ka);
+    } else {
+        Fat fa, fb;
+        fa.pw = pa; fa.res_ord = (uint32_t)ka; fa.crm = (uint32_t)(ka >> 32);
+        fb.pw = pb; fb.res_ord = (uint32_t)kb; fb.crm = (uint32_t)(kb >> 32);
+        const int o = orient(fa, fb);
+        m_ok = __ballot(o != 0); m_swap = __ballot(o == 2);
+    }
+    lmask m_valid = m_act & lm_ge_f64_sv(K.r2, s) & m_ok;  // rstar: inclusive
+    // distance levels: Le against the element pair's bounds, Lg against the fixed ones; L = 4 Le + Lg
+    const uint32_t eix = (pa & 0xF0u) | (pb & 0x0Fu);
+    const double t_clash = tb.s_clash[eix], t_cov = tb.s_cov[eix], t_vdw = tb.s_vdw[eix];
+    uint32_t L = 0;
+    asm("v_cmp_lt_f64_e32 vcc, %[s], %[tv]\n\t"
+        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+        "v_cmp_lt_f64_e32 vcc, %[s], %[tc]\n\t"
+        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+        "v_cmp_lt_f64_e32 vcc, %[s], %[tx]\n\t"
+        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+        "v_lshlrev_b32_e32 %[L], 2, %[L]\n\t"
+        "v_cmp_gt_f64_e32 vcc, %[k45], %[s]\n\t"
+        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+        "v_cmp_gt_f64_e32 vcc, %[k40], %[s]\n\t"
+        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+        "v_cmp_gt_f64_e32 vcc, %[k35], %[s]\n\t"
+        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc"
+        : [L] "+v"(L)
+        : [s] "v"(s), [tv] "v"(t_vdw), [tc] "v"(t_cov), [tx] "v"(t_clash), [k45] "s"(K.s_hphob), [k40] "s"(K.s_ion), [k35] "s"(K.s_polar)
+        : "vcc");
+    // W = (Pa & Qb) | (Pb & Qa): P is byte 1 of the pair word, Q byte 2
+    uint32_t w1, w2;
+    asm("v_and_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_and_b32_sdwa %1, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2"
+        : "=&v"(w1), "=&v"(w2) : "v"(pa), "v"(pb));
+    const uint32_t t = tb.lut[(L << 7) | w1 | w2];
+    // a probe decides: bit 30 & (either residue carries hydrogens), bit 29 & (residue tables present); bit 31 is never set
+    const lmask m_defer = lm_lt_u32_sv(0x1FFFFFFFu, t & (pa | pb | probe_bits)) & m_valid;
+    const uint32_t kind = t & 0x1FFFFFFFu;
+    if (wflags & kWaveContactsOnly) m_valid &= lm_lt_u32_sv(0u, kind) | m_defer;  // ARP_FLAG_CONTACTS_ONLY: no-interaction candidates are dropped
+    // (f32) of the correctly rounded f64 sqrt (kernels.hip dist_f32), the rare exact path behind a wave-uniform branch
+    const double r = (double)__frsqrt_rn((float)s);
+    const double y0 = s * r, hr = 0.5 * r;
+    double y = __fma_rn(__fma_rn(-y0, y0, s), hr, y0);
+    {
+        const uint32_t low = (uint32_t)__double_as_longlong(y) & 0x1FFFFFFFu;  // the 29 bits a cast to f32 drops
+        // s outside [2^-100, 2^100) (zero, non-finite), or y within 2048 f64 ulps of an f32 rounding boundary
+        const lmask m_exact = m_valid & (lm_lt_u32_sv(0x46300000u - 0x39B00000u - 1u, (uint32_t)__double2hiint(s) - 0x39B00000u) |
+                                         lm_gt_u32_sv(4097u, low - (0x10000000u - 2048u)));
+        if (m_exact) {
+            asm volatile("" ::: "memory");  // keep this a branch (no speculation of the long sequence)
+            if (lm_lane(m_exact, lane)) y = sqrt(s);
+        }
+    }
+    u32x4 rec;
+    rec.x = lm_select(m_swap, bzp.w, azp.w); rec.y = lm_select(m_swap, azp.w, bzp.w);
+    rec.z = __float_as_uint((float)y); rec.w = kind;
+    if (m_defer) {  // candidates whose rules need a probe go to the deferred pass (k_pairs_deferred), as global slot pairs
+        const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], (uint32_t)__popcll(m_defer), lane);
+        if (lm_lane(m_defer, lane)) {
+            const uint32_t dr = lm_rank(m_defer);
+            const unsigned long long p = dr < ds.n0 ? ds.pos0 + dr : ds.pos1 + (dr - ds.n0);
+            if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(slot0 + hl, nb); else atomicOr(&result[1], 8ull);
+        }
+        m_valid &= ~m_defer;
+    }
+    const uint32_t n = (uint32_t)__popcll(m_valid);
+    if (n) {  // compacted, coalesced store of the batch's records straight from registers
+        const Slots sl = alloc_chunked<kChunkRecords>(bl.alloc_state, &result[2], n, lane);
+        const uint32_t rank = lm_rank(m_valid);
+        if (sl.n0 == n && sl.pos0 + n <= tg.capacity) {  // one run inside the caller's buffer
+            lm_store_records(m_valid, reinterpret_cast<uint4 *>(tg.out) + sl.pos0, rank << 4, rec);
+        } else if (lm_lane(m_valid, lane)) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
+            uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
+            if (d) store_record(d, make_uint4(rec.x, rec.y, rec.z, rec.w));
+        }
+    }
+}
+
+// WAVES per block: kEWaves for inputs that fill the chip; 4 for small ones, whose few tasks then spread over more CUs
+// SPLIT: 1, or 4 = a task's five window kinds are shared out over four waves ({0, 1}, {2}, {3}, {4}), or 8 = two waves per kind set on
+// alternate 32-test runs: a small input has few tasks and each is a long chain of dependent round trips, so more waves on a
+// fraction of the chain each is what shortens the launch
+template <int WAVES, int SPLIT>
+__global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
+                                                                                           EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
+    __shared__ TablesE tb;
+    __shared__ WaveLdsE wl[WAVES];
+    __shared__ BlockLds bl;
+    load_tables_e(tb, dprm);
+    if (threadIdx.x == 0) {
+        bl.alloc_state = kAllocEmpty | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
+        bl.defer_state = kAllocEmpty | kDeferChunk;
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
+    const uint32_t wflags = (gp->all_both ? kWaveAllBoth : 0u) | ((dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u);
+    const uint32_t probe_bits = in.n_res != 0u ? (1u << 29) : 0u;  // residue tables present: CYS SG pairs in the covalent band get their dihedral probe
+    const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar};
+    const double r2m = gp->r2m;
+    WaveLdsE &w = wl[wave];
+    // task distribution as in k_pairs: block group (b mod 8) = one XCD = one contiguous eighth of the tasks, static first task per wave
+    const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
+    const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
+    uint32_t *ctr = task_ctr + (kEmit * 8 + group) * kTaskCtrStride;
+    const uint32_t queue_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)w.queue);
+    const uint32_t group_waves = ((gridDim.x - group + n_groups - 1u) / n_groups) * WAVES;
+    uint32_t t = g_lo + (blockIdx.x / n_groups) * WAVES + wave;
+#pragma unroll 1
+    while (t < g_hi) {
+        constexpr uint32_t kSubs = SPLIT == 8 ? 2u : 1u;  // SPLIT == 8: two waves per kind set, on alternate 32-test runs
+        const uint32_t slot0 = (t / (uint32_t)SPLIT) * 64u, part = (t % (uint32_t)SPLIT) / kSubs, sub = (t % (uint32_t)SPLIT) % kSubs;
+        const int k_lo = SPLIT == 1 ? 0 : (part == 0u ? 0 : (int)part + 1), k_hi = SPLIT == 1 ? 5 : (int)part + 2;  // window kinds of this wave-task
+        const uint32_t a = slot0 + lane;  // this lane's home slot
+        const bool have = a < n_heavy;
+        float4 home = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t cx = 0, cy = 0, cz = 0;
+        wave_lds_fence();  // the previous task's batches are done with the home records
+        {
+            u32x4 hxy = {0u, 0u, 0u, 0u}, hzp = {0u, 0u, 0u, 0u};
+            unsigned long long hkey = 0ull;
+            if (have) {
+                home = so.rec[a];
+                const Fat &f = fat_at<false>(so.fat, a);
+                const double fx = f.x, fy = f.y, fz = f.z;
+                hxy = u32x4{(uint32_t)__double2loint(fx), (uint32_t)__double2hiint(fx), (uint32_t)__double2loint(fy), (uint32_t)__double2hiint(fy)};
+                hzp = u32x4{(uint32_t)__double2loint(fz), (uint32_t)__double2hiint(fz), f.pw, f.orig};
+                hkey = ((unsigned long long)f.crm << 32) | f.res_ord;
+                const uint32_t c = f.cell;
+                cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
+            }
+            w.hxy[lane] = hxy; w.hzp[lane] = hzp; w.hkey[lane] = hkey;
+        }
+        const uint32_t xlo = cx > kx ? cx - kx : 0u, xhi = min(cx + kx, nx - 1);
+        // all five slot windows of this lane up front: ten independent loads in flight instead of five round trips
+        uint32_t wlo[5] = {0, 0, 0, 0, 0}, whi[5] = {0, 0, 0, 0, 0};
+        if (have) {
+            wlo[0] = a + 1; whi[0] = cell_start[(cz * ny + cy) * nx + xhi + 1];
+#pragma unroll
+            for (int k = 1; k < 5; k++) {
+                const int dy = (k == 1) ? 1 : (k - 3);
+                const uint32_t zz = cz + (k == 1 ? 0u : 1u);
+                const int yy = (int)cy + dy;
+                if (yy >= 0 && yy < (int)ny && zz < nzt) {
+                    const uint32_t r = (zz * ny + (uint32_t)yy) * nx;
+                    wlo[k] = cell_start[r + xlo]; whi[k] = cell_start[r + xhi + 1];
+                }
+            }
+        }
+        // per-lane constants of the prefilter: -2 h (exact in f32) and the threshold r2m - |h|^2, rounded up (DESIGN.md "Prefilter margin")
+        const float3 hm2 = make_float3(-2.0f * home.x, -2.0f * home.y, -2.0f * home.z);
+        const float thr = __double2float_ru(r2m - ((double)home.x * home.x + (double)home.y * home.y + (double)home.z * home.z));
+        const uint32_t lane_tag = lane << kESlotBits;
+        uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); drained at the end of the task
+#pragma unroll 1
+        for (int k = k_lo; k < k_hi; k++) {
+            uint32_t lo = wlo[0], hi = whi[0];
+#pragma unroll
+            for (int j = 1; j < 5; j++) if (k == j) { lo = wlo[j]; hi = whi[j]; }
+            const bool nonempty = lo < hi;
+            const uint32_t Lw = wave_min_u32(nonempty ? lo : 0xFFFFFFFFu), Hw = wave_max_u32(nonempty ? hi : 0u);
+            if (Lw >= Hw) continue;
+#pragma unroll 1
+            for (uint32_t cs = Lw; cs < Hw; cs += kEChunk) {
+                const uint32_t ce = min(cs + kEChunk, Hw);
+                const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
+                const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
+                if (!__any(len != 0u)) continue;
+                wave_lds_fence();  // previous chunk fully consumed
+                for (uint32_t p = cs + lane; p < ce; p += 64u) w.nrec[p - cs] = so.rec[p];
+                wave_lds_fence();
+                const uint32_t off = len ? j0 - cs : 0u;
+                uint32_t it0 = sub * kEAcc;  // (wave-uniform)  SPLIT == 8: the partner wave takes every other run of kEAcc tests
+                bool more = kSubs == 1u || __any(it0 < len);
+#pragma unroll 1
+                while (more) {
+                    // Phase 1, one run: up to kEAcc prefilter tests per lane in groups of kEGroup, results pushed into the lane's mask word
+                    // (test q of the run ends up in bit nacc - 1 - q).  Lanes whose window is exhausted read records 0..7 of the chunk
+                    // (any staged data will do: their bits are dropped below).
+                    const uint32_t acc0 = it0;
+                    uint32_t mask = 0, nacc = 0;
+#pragma unroll 1
+                    do {
+                        const float4 *win = w.nrec + (it0 < len ? off + it0 : 0u);
+#pragma unroll
+                        for (uint32_t u0 = 0; u0 < kEGroup; u0 += kReadAhead) {
+                            float rx[kReadAhead], ry[kReadAhead], rz[kReadAhead], rw[kReadAhead];
+#pragma unroll
+                            for (uint32_t u = 0; u < kReadAhead; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; rw[u] = r.w; }
+                            // |n|^2 - 2 n.h against thr = r2m - |h|^2; the FMAs link-major over the tests in flight so that neighbours are independent
+                            float acc[kReadAhead];
+#pragma unroll
+                            for (uint32_t u = 0; u < kReadAhead; ++u) acc[u] = __fmaf_rn(rx[u], hm2.x, rw[u]);
+#pragma unroll
+                            for (uint32_t u = 0; u < kReadAhead; ++u) acc[u] = __fmaf_rn(ry[u], hm2.y, acc[u]);
+#pragma unroll
+                            for (uint32_t u = 0; u < kReadAhead; ++u) acc[u] = __fmaf_rn(rz[u], hm2.z, acc[u]);
+#pragma unroll
+                            for (uint32_t u = 0; u < kReadAhead; ++u) push_pass(mask, acc[u], thr);
+                        }
+                        it0 += kEGroup; nacc += kEGroup;
+                        more = __any(it0 < len);
+                    } while (more && nacc < kEAcc);
+                    // tests of this run past the lane's window end looked at other atoms: drop them
+                    const uint32_t rem = len > acc0 ? len - acc0 : 0u;
+                    if (rem < nacc) mask = rem ? mask & (0xFFFFFFFFu << (nacc - rem)) : 0u;
+                    // (bit 31 - lz <-> test q = lz - (32 - nacc) <-> neighbour slot cs + off + acc0 + q)
+                    const uint32_t tag = lane_tag + (cs + off + acc0 - (32u - nacc));
+                    while (__any(mask != 0u)) {
+                        const uint32_t q0 = __builtin_amdgcn_readfirstlane(qlen);
+                        const unsigned long long m = compact_round_e(mask, tag, queue_lds + 4u * q0);
+                        uint32_t q1 = q0 + (uint32_t)__popcll(m);
+                        if (q1 >= 64u) {
+                            q1 -= 64u;
+                            exact_batch_e<true>(K, tb, w, bl, so, q1, 64u, slot0, tg, result, lane, wflags, probe_bits);
+                        }
+                        qlen = q1;
+                    }
+                    if (kSubs > 1u) { it0 += (kSubs - 1u) * kEAcc; more = __any(it0 < len); }
+                }
+            }
+        }
+        if (qlen) exact_batch_e<false>(K, tb, w, bl, so, 0u, qlen, slot0, tg, result, lane, wflags, probe_bits);  // the home records go with the task: drain
+        uint32_t nxt_task = 0;
+        if (lane == 0) nxt_task = atomicAdd(ctr, 1u);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
+        t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);
+    }
+    emit_epilogue(bl, hole_list + blockIdx.x, tg);
+}
+
+// single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
+void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool skip_deferred) {
+    EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
+    const uint32_t tasks = (in.n + 63u) / 64u;
+    // few tasks: 4-wave blocks reach more CUs, and every task is shared out over four or eight waves (6bft: 128 tasks)
+    const bool small = tasks < 3072u, tiny = tasks < 768u;
+    const uint32_t split = tiny ? 8u : (small ? 4u : 1u);
+    const uint32_t per = small ? 4u : (uint32_t)kEWaves, cap = small ? 1536u : kEBlocks, want = (split * tasks + per - 1u) / per;
+    const uint32_t nb = want < 1 ? 1 : (want > cap ? cap : want);
+    if (prof) prof->begin("pairs_emit", st);
+#define ARP_LAUNCH_E(W, S) hipLaunchKernelGGL((k_emit<W, S>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
+                                              (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
+    if (small && split == 8u) ARP_LAUNCH_E(4, 8);
+    else if (small) ARP_LAUNCH_E(4, 4);
+    else ARP_LAUNCH_E(kEWaves, 1);
+#undef ARP_LAUNCH_E
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred);
+}
+static_assert(kEBlocks + 384u <= kMaxHoles && 1536u + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");

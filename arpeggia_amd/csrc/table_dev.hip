@@ -144,13 +144,14 @@ __global__ __launch_bounds__(64) void k_ring_atom(uint32_t n_rings, const RingEn
     const ResKeyD rk{ring.model_serial, ring.chain_rank, ring.ord, (ring.flags & 1u) != 0u, (ring.flags & 2u) != 0u};
     const GridParams g = *gp;
     if (g.model_org || g.n_heavy == 0u) return;  // (a packed batch's grid never reaches the table path)
-    const double r2 = radius * radius, rho = fabs(radius) * g.inv_edge * (1.0 + 1e-9) + 1e-9;  // (the reference only ever uses the square: complex.rs:303)
+    const double r2 = radius * radius;  // (the reference only ever uses the square: complex.rs:303)
+    const double inv[3] = {g.inv_edge_x, g.inv_edge, g.inv_edge};  // cells are kx times finer along x
     // cells the sphere can touch, per axis: floor(f - rho) .. floor(f + rho) of the centre's cell coordinate f, clamped to the grid
     uint32_t lo[3], hi[3];
     const uint32_t dim[3] = {g.nx, g.ny, g.nz};
     const double org[3] = {g.ox, g.oy, g.oz};
     for (int k = 0; k < 3; k++) {
-        const double f = (pl.c[k] - org[k]) * g.inv_edge;
+        const double f = (pl.c[k] - org[k]) * inv[k], rho = fabs(radius) * inv[k] * (1.0 + 1e-9) + 1e-9;
         const double a = floor(f - rho), b = floor(f + rho);
         if (!(b >= 0.0) || !(a <= (double)(dim[k] - 1u))) return;  // the sphere misses the grid (or a non-finite centre)
         lo[k] = a > 0.0 ? (uint32_t)a : 0u;

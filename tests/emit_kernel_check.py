@@ -1,5 +1,5 @@
 """Parity of ONE emit kernel variant against the oracle, in a process of its own (ARP_EMIT_KERNEL is read once per process).
-Run by tests/test_gpu_parity.py::test_alternative_emit_kernels; usage: ARP_EMIT_KERNEL=gather|lds|blk|h python tests/emit_kernel_check.py"""
+Run by tests/test_gpu_parity.py::test_alternative_emit_kernels; usage: ARP_EMIT_KERNEL=gather python tests/emit_kernel_check.py"""
 import sys
 from pathlib import Path
 
