@@ -111,11 +111,16 @@ DEVFN unsigned long long wave_first_u64(unsigned long long v) {
 }
 // Only the LDS atomic itself runs in lane 0; everything derived from its (broadcast) result is wave-uniform, so the
 // position arithmetic lands on the scalar unit instead of costing vector issue slots for one live lane.
+// The LDS atomic is a round trip of several hundred cycles under load, in the middle of a batch's dependent chain: alloc_issue starts it
+// (lane 0) as soon as the record count is known, alloc_finish picks the answer up after the classification has been computed.
+DEVFN unsigned long long alloc_issue(unsigned long long &state, uint32_t n, uint32_t lane) {
+    unsigned long long old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&state, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return old;  // (lane 0 holds the answer)
+}
 template <uint32_t CHUNK>
-DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane) {
+DEVFN Slots alloc_finish(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane, unsigned long long old) {
     for (;;) {
-        unsigned long long old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(&state, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = wave_first_u64(old);
         const uint32_t used = (uint32_t)old, chunk = (uint32_t)(old >> 32);
         if (used + n <= CHUNK) return Slots{(unsigned long long)chunk * CHUNK + used, 0ull, n};
@@ -132,7 +137,12 @@ DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head,
         // exhausted while another wave refills: sleep on the LDS word until the new chunk is published, then retry
         while ((uint32_t)(wave_first_u64(__hip_atomic_load(&state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) == chunk)
             __builtin_amdgcn_s_sleep(2);
+        old = alloc_issue(state, n, lane);
     }
+}
+template <uint32_t CHUNK>
+DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane) {
+    return alloc_finish<CHUNK>(state, g_head, n, lane, alloc_issue(state, n, lane));
 }
 
 constexpr uint32_t kWaveAllBoth = 1u, kWaveContactsOnly = 2u;  // wave-uniform switches of process_batch, kept in a scalar register
@@ -460,12 +470,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
     emit_epilogue(bl, hole_list + blockIdx.x, tg);
 }
 
-// The deferred pass of the fast ordered fill: {entry, position} pairs; the probes decide the kind, which is patched in place.
+// The deferred pass of the fast ordered fill and of the single-pass emitter's all-candidates mode: {entry, position} pairs; the probes
+// decide the kind, which is patched in place (positions beyond the caller's capacity live in the engine's scratch until k_fixup).
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_patch_deferred(DevAtoms in, const DevParams *dprm, Sorted so, EmitTarget tg,
                                                                          unsigned long long *result) {
     __shared__ LdsParams prm;
-    load_lds_params(prm, dprm, nullptr);
     const unsigned long long n = min(result[3] * kDeferChunk, tg.defer_cap) / 2ull;  // {entry, position} pairs
+    if (n == 0ull) return;  // nothing was deferred (no hydrogens, no close CYS SG pair)
+    load_lds_params(prm, dprm, nullptr);
     const uint4 *list = reinterpret_cast<const uint4 *>(tg.defer_list);
     for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (unsigned long long)gridDim.x * blockDim.x) {
         const uint4 e = list[q];
@@ -475,7 +487,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_patch_deferred(DevAtoms
         const bool swap = orient(a, b) == 2;
         const uint32_t kind = classify<true>(in, prm, s, a, b, swap, result);
         const unsigned long long pos = ((unsigned long long)e.w << 32) | e.z;
-        reinterpret_cast<uint32_t *>(tg.out + pos)[3] = kind;
+        uint4 *d = emit_slot(tg, pos, result);
+        if (d) reinterpret_cast<uint32_t *>(d)[3] = kind;
     }
 }
 
@@ -665,19 +678,23 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 }
 
 // what follows either emit kernel: the deferred probe pass (unless the engine's memo says this input defers nothing) and the hole fix-up
-static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const EmitTarget &tg, uint32_t nb, hipStream_t st, Profiler *prof, bool skip_deferred) {
+// patch: the emit kernel wrote the deferred candidates as records with a placeholder kind (k_emit, all candidates): k_patch_deferred decides
+// the kinds in place; otherwise k_pairs_deferred classifies and emits them itself (its blocks add holes of their own)
+static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const EmitTarget &tg, uint32_t nb, hipStream_t st, Profiler *prof, bool skip_deferred, bool patch) {
     if (prof) prof->end(st);
     if (!skip_deferred) {
         if (prof) prof->begin("pairs_deferred", st);
-        hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result);
+        if (patch) hipLaunchKernelGGL(k_patch_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.result);
+        else hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result);
         if (prof) prof->end(st);
     }
     if (prof) prof->begin("pairs_fixup", st);
-    hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, skip_deferred ? nb : nb + kDeferBlocks, (const GridParams *)ws.grid, tg,
-                       ws.result, skip_deferred ? 1u : 0u);
+    hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, (skip_deferred || patch) ? nb : nb + kDeferBlocks,
+                       (const GridParams *)ws.grid, tg, ws.result, skip_deferred ? 1u : 0u);
     if (prof) prof->end(st);
 }
-void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool skip_deferred);
+void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+                   bool skip_deferred);
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
                  bool skip_deferred) {
@@ -689,7 +706,7 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     // The default is k_emit (pairs_emit.inl).  This file's k_pairs<kEmit> -- both exact operands gathered, 8-byte queue entries -- is the
     // one alternative kept: it takes the inputs beyond k_emit's 2^26 slots, and ARP_EMIT_KERNEL=gather selects it for the parity suite.
     static const bool gather = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'g'; }();
-    if (!gather && in.n < (1u << 26) - 64u) { launch_emit_e(in, ws, out, capacity, st, prof, skip_deferred); return; }
+    if (!gather && in.n < (1u << 26) - 64u) { launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred); return; }
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1600)
         const char *e = getenv("ARP_EMIT_BLOCKS");
@@ -701,5 +718,5 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     hipLaunchKernelGGL((k_pairs<kEmit, false>), dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
                        (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,
                        ws.task_ctr, ws.result);
-    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred);
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, false);
 }

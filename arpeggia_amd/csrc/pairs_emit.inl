@@ -64,28 +64,37 @@ DEVFN void load_tables_e(TablesE &tb, const DevParams *dprm) {
     for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) tb.lut[k] = pair_lut2_entry(k);
 }
 
-// compact_round (pairs.inl) with 4-byte entries: every lane with a surviving test appends tag + (count of leading zeros of its mask) at
-// byte address qaddr + 4 * (its rank among those lanes) and clears that bit.  Returns the ballot of the lanes that appended.
-DEVFN unsigned long long compact_round_e(uint32_t &mask, uint32_t tag, uint32_t qaddr) {
-    unsigned long long m, save;
-    uint32_t t, lz, ent, bm;
+// Compaction rounds as one loop in assembly.  Every round, each lane with a surviving test (mask != 0) appends tag + (count of leading
+// zeros of its mask) -- home lane << 26 | neighbour slot -- at the queue tail + 4 * (its rank among those lanes) and clears that bit;
+// qbyte is the LDS byte address of the tail.  Returns when no lane has a test left or when the queue holds a full batch (qbyte >= qfull).
+// Left to the compiler the same loop costs ~24 instructions per round (address rebuilt from an entry count, lane mask copied twice, loop
+// condition recomputed); here 7 vector + 5 scalar + the LDS write + 2 branches.  A wave issues roughly one instruction per 5-9 cycles
+// whatever its kind (tests/microbench/valu_rate.hip), and a task runs ~60 rounds.
+DEVFN void compact_rounds_e(uint32_t &mask, uint32_t tag, uint32_t &qbyte, uint32_t qfull) {
+    unsigned long long save;
+    uint32_t t, lz, ent, bm, c;
     asm volatile(
+        "1:\n\t"
         "v_cmp_ne_u32 vcc, 0, %[mask]\n\t"
+        "s_cbranch_vccz 2f\n\t"
         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
         "v_ffbh_u32 %[lz], %[mask]\n\t"
-        "v_lshl_add_u32 %[t], %[t], 2, %[qaddr]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[qb]\n\t"
         "v_add_u32 %[ent], %[tag], %[lz]\n\t"
         "v_lshrrev_b32 %[bm], %[lz], %[top]\n\t"
-        "s_mov_b64 %[m], vcc\n\t"
+        "s_bcnt1_i32_b64 %[c], vcc\n\t"
         "s_and_saveexec_b64 %[save], vcc\n\t"
         "ds_write_b32 %[t], %[ent]\n\t"
         "v_xor_b32 %[mask], %[mask], %[bm]\n\t"
-        "s_mov_b64 exec, %[save]"
-        : [mask] "+v"(mask), [t] "=&v"(t), [lz] "=&v"(lz), [ent] "=&v"(ent), [bm] "=&v"(bm), [m] "=&s"(m), [save] "=&s"(save)
-        : [tag] "v"(tag), [qaddr] "s"(qaddr), [top] "s"(0x80000000u)
-        : "vcc", "memory");
-    return m;
+        "s_mov_b64 exec, %[save]\n\t"
+        "s_lshl2_add_u32 %[qb], %[c], %[qb]\n\t"
+        "s_cmp_lt_u32 %[qb], %[qf]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "2:"
+        : [mask] "+v"(mask), [qb] "+s"(qbyte), [t] "=&v"(t), [lz] "=&v"(lz), [ent] "=&v"(ent), [bm] "=&v"(bm), [c] "=&s"(c), [save] "=&s"(save)
+        : [tag] "v"(tag), [top] "s"(0x80000000u), [qf] "s"(qfull)
+        : "vcc", "scc", "memory");
 }
 
 struct ConstsE { double r2, s_hphob, s_ion, s_polar; };  // wave-uniform: scalar registers
@@ -125,7 +134,12 @@ DEVFN void lm_store_records(lmask m, uint4 *base, uint32_t byte_off, const u32x4
 // Phase 2 on queue entries [first, first + count), count <= 64 (FULL: count == 64): home operands out of LDS, neighbour operands gathered
 // (40 of the 48 bytes of the exact record).  Every lane computes everything -- the lanes beyond count on entry 0 (home lane 0, slot 0: in
 // bounds) -- and only the stores are predicated.
-template <bool FULL>
+// ONLY = ARP_FLAG_CONTACTS_ONLY: candidates without a row are dropped, so a record's place is only known once its rows are; the pairs
+// a probe has to decide go to k_pairs_deferred, which emits them itself.  All candidates (!ONLY): every candidate is a record, so the
+// output positions are requested from the block's allocator as soon as the cutoff test is in -- the answer travels while the rows are
+// computed -- and a pair that needs a probe is written with kind 0 at its final position and listed {slots, position} for
+// k_patch_deferred (pairs.inl).
+template <bool FULL, bool ONLY>
 DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, const Sorted &so, uint32_t first, uint32_t count, uint32_t slot0,
                          const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
     first = __builtin_amdgcn_readfirstlane(first); count = __builtin_amdgcn_readfirstlane(count);  // (wave-uniform by construction: say so)
@@ -160,6 +174,9 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
         m_ok = __ballot(o != 0); m_swap = __ballot(o == 2);
     }
     lmask m_valid = m_act & lm_ge_f64_sv(K.r2, s) & m_ok;  // rstar: inclusive
+    const uint32_t n_early = ONLY ? 0u : (uint32_t)__popcll(m_valid);
+    unsigned long long a_old = 0ull;
+    if (!ONLY && n_early) a_old = alloc_issue(bl.alloc_state, n_early, lane);
     // distance levels: Le against the element pair's bounds, Lg against the fixed ones; L = 4 Le + Lg
     const uint32_t eix = (pa & 0xF0u) | (pb & 0x0Fu);
     const double t_clash = tb.s_clash[eix], t_cov = tb.s_cov[eix], t_vdw = tb.s_vdw[eix];
@@ -188,8 +205,8 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
     const uint32_t t = tb.lut[(L << 7) | w1 | w2];
     // a probe decides: bit 30 & (either residue carries hydrogens), bit 29 & (residue tables present); bit 31 is never set
     const lmask m_defer = lm_lt_u32_sv(0x1FFFFFFFu, t & (pa | pb | probe_bits)) & m_valid;
-    const uint32_t kind = t & 0x1FFFFFFFu;
-    if (wflags & kWaveContactsOnly) m_valid &= lm_lt_u32_sv(0u, kind) | m_defer;  // ARP_FLAG_CONTACTS_ONLY: no-interaction candidates are dropped
+    uint32_t kind = t & 0x1FFFFFFFu;
+    if (ONLY) m_valid &= lm_lt_u32_sv(0u, kind) | m_defer;  // no-interaction candidates are dropped
     // (f32) of the correctly rounded f64 sqrt (kernels.hip dist_f32), the rare exact path behind a wave-uniform branch
     const double r = (double)__frsqrt_rn((float)s);
     const double y0 = s * r, hr = 0.5 * r;
@@ -206,7 +223,32 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
     }
     u32x4 rec;
     rec.x = lm_select(m_swap, bzp.w, azp.w); rec.y = lm_select(m_swap, azp.w, bzp.w);
-    rec.z = __float_as_uint((float)y); rec.w = kind;
+    rec.z = __float_as_uint((float)y);
+    if (!ONLY) {
+        if (!n_early) return;
+        const Slots sl = alloc_finish<kChunkRecords>(bl.alloc_state, &result[2], n_early, lane, a_old);
+        const uint32_t rank = lm_rank(m_valid);
+        if (m_defer) {  // rare: the probe pass patches these kinds in place
+            const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], 2u * (uint32_t)__popcll(m_defer), lane);  // (even counts: a pair never straddles a chunk)
+            if (lm_lane(m_defer, lane)) {
+                const unsigned long long pos = rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0);
+                const uint32_t dr = 2u * lm_rank(m_defer);
+                const unsigned long long p = dr < ds.n0 ? ds.pos0 + dr : ds.pos1 + (dr - ds.n0);
+                if (p + 1ull < tg.defer_cap) { tg.defer_list[p] = make_uint2(slot0 + hl, nb); tg.defer_list[p + 1ull] = make_uint2((uint32_t)pos, (uint32_t)(pos >> 32)); }
+                else atomicOr(&result[1], 8ull);
+                kind = 0u;
+            }
+        }
+        rec.w = kind;
+        if (sl.n0 == n_early && sl.pos0 + n_early <= tg.capacity) {  // one run inside the caller's buffer
+            lm_store_records(m_valid, reinterpret_cast<uint4 *>(tg.out) + sl.pos0, rank << 4, rec);
+        } else if (lm_lane(m_valid, lane)) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
+            uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
+            if (d) store_record(d, make_uint4(rec.x, rec.y, rec.z, rec.w));
+        }
+        return;
+    }
+    rec.w = kind;
     if (m_defer) {  // candidates whose rules need a probe go to the deferred pass (k_pairs_deferred), as global slot pairs
         const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], (uint32_t)__popcll(m_defer), lane);
         if (lm_lane(m_defer, lane)) {
@@ -233,7 +275,7 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
 // SPLIT: 1, or 4 = a task's five window kinds are shared out over four waves ({0, 1}, {2}, {3}, {4}), or 8 = two waves per kind set on
 // alternate 32-test runs: a small input has few tasks and each is a long chain of dependent round trips, so more waves on a
 // fraction of the chain each is what shortens the launch
-template <int WAVES, int SPLIT>
+template <int WAVES, int SPLIT, bool ONLY>
 __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
                                                                                            EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     __shared__ TablesE tb;
@@ -247,7 +289,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
-    const uint32_t wflags = (gp->all_both ? kWaveAllBoth : 0u) | ((dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u);
+    const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
     const uint32_t probe_bits = in.n_res != 0u ? (1u << 29) : 0u;  // residue tables present: CYS SG pairs in the covalent band get their dihedral probe
     const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar};
     const double r2m = gp->r2m;
@@ -304,7 +346,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
         const float3 hm2 = make_float3(-2.0f * home.x, -2.0f * home.y, -2.0f * home.z);
         const float thr = __double2float_ru(r2m - ((double)home.x * home.x + (double)home.y * home.y + (double)home.z * home.z));
         const uint32_t lane_tag = lane << kESlotBits;
-        uint32_t qlen = 0;   // phase-1 survivors waiting in w.queue (wave-uniform); drained at the end of the task
+        uint32_t qbyte = queue_lds;  // LDS byte address of the queue tail (wave-uniform): the phase-1 survivors waiting in w.queue; drained at the end of the task
 #pragma unroll 1
         for (int k = k_lo; k < k_hi; k++) {
             uint32_t lo = wlo[0], hi = whi[0];
@@ -359,21 +401,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                     if (rem < nacc) mask = rem ? mask & (0xFFFFFFFFu << (nacc - rem)) : 0u;
                     // (bit 31 - lz <-> test q = lz - (32 - nacc) <-> neighbour slot cs + off + acc0 + q)
                     const uint32_t tag = lane_tag + (cs + off + acc0 - (32u - nacc));
-                    while (__any(mask != 0u)) {
-                        const uint32_t q0 = __builtin_amdgcn_readfirstlane(qlen);
-                        const unsigned long long m = compact_round_e(mask, tag, queue_lds + 4u * q0);
-                        uint32_t q1 = q0 + (uint32_t)__popcll(m);
-                        if (q1 >= 64u) {
-                            q1 -= 64u;
-                            exact_batch_e<true>(K, tb, w, bl, so, q1, 64u, slot0, tg, result, lane, wflags, probe_bits);
-                        }
-                        qlen = q1;
+                    for (;;) {
+                        uint32_t qb = __builtin_amdgcn_readfirstlane(qbyte);  // (wave-uniform by construction: say so)
+                        compact_rounds_e(mask, tag, qb, queue_lds + 256u);
+                        qbyte = qb;
+                        if (qbyte < queue_lds + 256u) break;  // every test of the run is in the queue
+                        qbyte -= 256u;                        // a full batch: the 64 entries at the tail
+                        exact_batch_e<true, ONLY>(K, tb, w, bl, so, (qbyte - queue_lds) >> 2, 64u, slot0, tg, result, lane, wflags, probe_bits);
                     }
                     if (kSubs > 1u) { it0 += (kSubs - 1u) * kEAcc; more = __any(it0 < len); }
                 }
             }
         }
-        if (qlen) exact_batch_e<false>(K, tb, w, bl, so, 0u, qlen, slot0, tg, result, lane, wflags, probe_bits);  // the home records go with the task: drain
+        if (qbyte != queue_lds) exact_batch_e<false, ONLY>(K, tb, w, bl, so, 0u, (qbyte - queue_lds) >> 2, slot0, tg, result, lane, wflags, probe_bits);  // the home records go with the task: drain
         uint32_t nxt_task = 0;
         if (lane == 0) nxt_task = atomicAdd(ctr, 1u);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);
@@ -382,7 +422,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
 }
 
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
-void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool skip_deferred) {
+void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+                   bool skip_deferred) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t tasks = (in.n + 63u) / 64u;
     // few tasks: 4-wave blocks reach more CUs, and every task is shared out over four or eight waves (6bft: 128 tasks)
@@ -391,12 +432,18 @@ void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
     const uint32_t per = small ? 4u : (uint32_t)kEWaves, cap = small ? 1536u : kEBlocks, want = (split * tasks + per - 1u) / per;
     const uint32_t nb = want < 1 ? 1 : (want > cap ? cap : want);
     if (prof) prof->begin("pairs_emit", st);
-#define ARP_LAUNCH_E(W, S) hipLaunchKernelGGL((k_emit<W, S>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
-                                              (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
-    if (small && split == 8u) ARP_LAUNCH_E(4, 8);
-    else if (small) ARP_LAUNCH_E(4, 4);
-    else ARP_LAUNCH_E(kEWaves, 1);
+#define ARP_LAUNCH_E(W, S, O) hipLaunchKernelGGL((k_emit<W, S, O>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
+                                                 (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
+    if (contacts_only) {
+        if (small && split == 8u) ARP_LAUNCH_E(4, 8, true);
+        else if (small) ARP_LAUNCH_E(4, 4, true);
+        else ARP_LAUNCH_E(kEWaves, 1, true);
+    } else {
+        if (small && split == 8u) ARP_LAUNCH_E(4, 8, false);
+        else if (small) ARP_LAUNCH_E(4, 4, false);
+        else ARP_LAUNCH_E(kEWaves, 1, false);
+    }
 #undef ARP_LAUNCH_E
-    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred);
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only);
 }
 static_assert(kEBlocks + 384u <= kMaxHoles && 1536u + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");
