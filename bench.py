@@ -8,12 +8,17 @@ pair table) over synthetic structures already resident in HBM.
               --gpus N every rank runs its own same-sized cloud ("scaling": "weak"): the path shards over independent structures,
               there is no data-path collective; torch.distributed only carries the barrier and the max/sum of the timings.
   `s1`        the same pass on the chemistry-faithful S1 cloud of the same size ("the headline run reports both").
+  `s2_1e5`, `s1_1e5`   BASELINE.json configs[2]: the 10^5-atom clouds (pairs/s, GB/s, roofline fraction).
+  `files`     BASELINE.json configs[0..1]: test-data 1ubq and 6bft through the same pass, resident on the device: us per call on the
+              stream, classified pairs, and the rows / warm wall time of the table path (arp_get_contacts) on the same files.
   `batch5k`   BASELINE.json configs[4]: a batch of ~5k-atom S1 structures (atoms ~ N(5000, 500^2) clipped to [3000, 7000]), dealt
               longest-first over the ranks (1250 per rank by default: 10^4 at 8 GPUs), each rank's share packed into one resident
               multi-model SoA; plus, on rank 0, the host-inclusive figure of arp_contacts_atomic_batch on 512 of them (PCIe both ways).
   `--workload batch5k` makes that batch the `value` instead (total size --structures, strong scaling over the ranks).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the context's stream) and `cpu_baseline`
+Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline`.  `roofline.frac` is SURVEY.md 8(d)'s quantity: the algorithmic bytes
+of one step over the device time of the WHOLE launch sequence (grid build + search/classify/emit + probe pass + hole fix-up, HIP events on
+the context's stream); `roofline.kernel_frac` is the same bytes over the dominant kernel alone.  `cpu_baseline`: see cpu_baseline()
 (the oracle -- this repo's C restatement, "port" -- on a bounded sample, one thread and all host threads; N=1 only).
 """
 from __future__ import annotations
@@ -134,17 +139,21 @@ def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, p
 
 
 def roofline_of(n_atoms, n_pairs, acc, dev_ms, traffic=None):
-    """algorithmic bytes = 36 B per atom read once + 16 B per classified pair written."""
+    """algorithmic bytes = 36 B per atom read once + 16 B per classified pair written; t_kernel = grid build + search /
+    classify / emit + second-pass kernels.  `frac` / `achieved` are over that whole launch sequence, `kernel_frac` / `kernel_achieved` over
+    the dominant kernel alone."""
     if not acc:  # --profile-steps 0 (external profiler runs): fall back to the whole device-side step
         acc = {"pipeline": dev_ms}
     dom = max(acc, key=acc.get)
     alg_bytes = 36.0 * n_atoms + 16.0 * n_pairs
     dom_ms, pipeline_ms = acc[dom], sum(acc.values())
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (pipeline_ms * 1e-3) / 1e9
+    kernel_achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     return {
-        "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "algorithmic_bytes": alg_bytes, "kernel_ms": dom_ms,
-        "pipeline_ms": pipeline_ms, "pipeline_frac": alg_bytes / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "scope": "whole launch sequence of one step (SURVEY.md 8d t_kernel): " + " + ".join(acc),
+        "algorithmic_bytes": alg_bytes, "pipeline_ms": pipeline_ms,
+        "kernel": dom, "kernel_ms": dom_ms, "kernel_achieved": kernel_achieved, "kernel_frac": kernel_achieved / HBM_PEAK_GBS,
         "kernels_ms": acc,
     }
 
@@ -157,23 +166,20 @@ def batch5k_sizes(n_structures: int):
 
 
 def batch5k_share(aa, synth, sizes, mine, pool=48):
-    """SoAs of this rank's structures.  Generating 10^4 distinct structures would take minutes of numpy time per run, so `pool`
-    distinct S1 structures per rank (sizes spread over the share's size range) stand in for the rest; every one is still an
-    independent structure of its own model in the pack."""
+    """SoAs of this rank's structures.  Generating 10^4 distinct structures would take minutes of numpy time per run, so `pool` distinct
+    S1 structures (sizes spread over the WHOLE batch's size range, the same on every rank) stand in for the rest: structure k is the pool
+    member closest in size, whatever rank it lands on, so the job's pair total does not depend on the number of ranks.  Every one is
+    still an independent structure of its own model in the pack."""
     import numpy as np
 
-    order = sorted(mine, key=lambda k: sizes[k])
-    picks = [order[int(round(q))] for q in np.linspace(0, len(order) - 1, min(pool, len(order)))]
+    order = sorted(range(len(sizes)), key=lambda k: sizes[k])
+    picks = sorted({order[int(round(q))] for q in np.linspace(0, len(order) - 1, min(pool, len(order)))}, key=lambda k: sizes[k])
+    need = {min(picks, key=lambda q: (abs(int(sizes[q]) - int(sizes[k])), q)) for k in mine}
     made = {}
-    for k in picks:
+    for k in need:
         rec = synth.gen_s1(int(sizes[k]), seed=SEED + 5 + k)
         made[k] = aa.Structure.from_records(rec, hierarchy=True).soa("/")
-    sized = sorted(made, key=lambda k: sizes[k])
-    soas = []
-    for k in mine:  # the stand-in closest in size
-        j = min(sized, key=lambda q: abs(int(sizes[q]) - int(sizes[k])))
-        soas.append(made[j])
-    return soas
+    return [made[min(picks, key=lambda q: (abs(int(sizes[q]) - int(sizes[k])), q))] for k in mine]
 
 
 def cpu_baseline(n_atoms: int, workload: str):
@@ -215,7 +221,7 @@ def cpu_baseline(n_atoms: int, workload: str):
         "sample": f"{workload.upper()} synthetic cloud, {n_atoms} atoms -> {len(pairs)} pairs, grid search + per-pair rules, "
                   f"{dt:.1f} s on 1 of {os.cpu_count()} host threads",
         "all_cores": {"value": sum(counts) / dt_all, "cores": threads,
-                      "sample": f"{threads} threads, each one independent 100000-atom cloud ({counts[0]} pairs), {dt_all:.1f} s"},
+                      "sample": f"{threads} of {os.cpu_count()} host threads, each one independent 100000-atom cloud ({counts[0]} pairs), {dt_all:.1f} s"},
         "reference_toolchain": cargo or "cargo not found on this box: the reference (Rust) cannot be built or timed here",
         "note": "restatement CPU baseline (oracle/arp_oracle.c), not the reference binary",
     }
@@ -263,8 +269,9 @@ def main():
     prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only)
     check = not args.no_check
 
-    def cloud(workload):  # one structure per rank, its own seed: independent structures shard with no exchange
-        rec = getattr(synth, f"gen_{workload}")(args.atoms, seed=SEED + (4 if workload == "s2" else 3) + 1000 * rank)
+    def cloud(workload, atoms=None):  # one structure per rank, its own seed: independent structures shard with no exchange
+        atoms = atoms or args.atoms
+        rec = getattr(synth, f"gen_{workload}")(atoms, seed=SEED + (4 if workload == "s2" else 3) + 1000 * rank + (0 if atoms == args.atoms else 7))
         order = os.environ.get("ARP_BENCH_ORDER")  # diagnostic: the same cloud with its atoms in another input order
         if order:
             import numpy as np
@@ -295,7 +302,8 @@ def main():
             wall += w; dev_ms += d; n_pairs += npair; n_atoms += na
             for k, v in a.items():
                 acc[k] = acc.get(k, 0.0) + v
-        label = f"batch of {total} S1 structures of ~5k atoms (N(5000, 500^2) clipped to [3000, 7000]), {n_mine} on this rank as one resident multi-model pack"
+        label = (f"batch of {total} S1 structures of ~5k atoms (N(5000, 500^2) clipped to [3000, 7000]), {n_mine} on this rank as one resident multi-model pack; "
+                 f"up to 48 distinct generated structures (one pool, the same on every rank) stand in for the rest")
         scaling = "strong" if args.structures else "weak"
     else:
         wall, dev_ms, n_pairs, acc, n_atoms = measure_resident(aa, _lib, torch, dev, dev_index, cloud(args.workload), prm, args.steps, args.warmup,
@@ -308,11 +316,38 @@ def main():
             w2max, p2all = reduce_job(dist, red_dev, w2, p2)
             sub[other] = {"workload": f"{other.upper()} synthetic {n2}-atom cloud per GPU", "atoms_per_gpu": n2, "pairs_per_gpu": p2,
                           "value": p2all * args.steps / w2max, "ms_per_step": w2max / args.steps * 1e3, "roofline": roofline_of(n2, p2, a2, d2)}
+            # BASELINE config 3: the 10^5-atom clouds (rank 0 only: they are small, and the multi-rank job is about configs 4 and 5)
+            if rank == 0:
+                for wl in ("s2", "s1"):
+                    w3, d3, p3, a3, n3 = measure_resident(aa, _lib, torch, dev, dev_index, cloud(wl, 100_000), prm, max(args.steps, 50), args.warmup, args.profile_steps,
+                                                          lambda: torch.cuda.synchronize(dev), check)
+                    sub[f"{wl}_1e5"] = {"workload": f"{wl.upper()} synthetic {n3}-atom cloud, 1 GPU (BASELINE config 3)", "atoms_per_gpu": n3, "pairs_per_gpu": p3,
+                                        "value": p3 * max(args.steps, 50) / w3, "unit": "classified atom-pairs/s", "ms_per_step": w3 / max(args.steps, 50) * 1e3,
+                                        "roofline": roofline_of(n3, p3, a3, d3)}
+                # BASELINE configs 1-2: the reference's own test files, resident on the device (launch-bound: microseconds, not a roofline)
+                files = {}
+                for name in ("1ubq", "6bft"):
+                    path = str(ROOT / "tests" / "data" / f"{name}.pdb")
+                    st = aa.load_model(path)
+                    wf, df, pf, af, nf = measure_resident(aa, _lib, torch, dev, dev_index, st.soa("/"), prm, 200, 10, args.profile_steps, lambda: torch.cuda.synchronize(dev), check)
+                    cf = aa.Context(dev_index)
+                    table = cf.get_contacts(st, "/", 0.1, 6.5)  # first call: uploads the resident copy, fits planes, ranks entities
+                    best = None
+                    for _ in range(20):
+                        t0 = time.perf_counter()
+                        table = cf.get_contacts(st, "/", 0.1, 6.5)
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None else min(best, dt)
+                    files[name] = {"atoms": nf, "pairs": pf, "us_per_call_on_stream": df * 1e3, "us_per_call_wall": wf / 200 * 1e6, "kernels_us": {k: v * 1e3 for k, v in af.items()},
+                                   "table_rows": int(len(table["model"])), "get_contacts_warm_us": best * 1e6}
+                sub["files"] = {"workload": "tests/data/1ubq.pdb and 6bft.pdb (= the reference's test-data), groups='/', vdw_comp=0.1, dist_cutoff=6.5: the pair pass on "
+                                            "device-resident arrays (200 calls on the stream) and the whole table (arp_get_contacts, best of 20 warm calls, host wall)", **files}
             packs, n_mine = batch(1250 * world)
             wb, db, pb, ab, nb = measure_resident(aa, _lib, torch, dev, dev_index, packs[0], prm, args.steps, args.warmup, args.profile_steps, barrier, check)
             wbmax, pball = reduce_job(dist, red_dev, wb, pb)
             sub["batch5k"] = {"workload": f"BASELINE config 5 shape: {1250 * world} S1 structures of ~5k atoms over {world} GPU(s), longest-first deal, "
-                                          f"{n_mine} on rank 0 as one resident multi-model pack", "structures": 1250 * world, "atoms_per_gpu": nb, "pairs_per_gpu": pb,
+                                          f"{n_mine} on rank 0 as one resident multi-model pack; up to 48 distinct generated structures (one pool, the same on every rank) stand in "
+                                          f"for the rest (each still its own model of the pack)", "structures": 1250 * world, "atoms_per_gpu": nb, "pairs_per_gpu": pb,
                               "value": pball * args.steps / wbmax, "unit": "classified atom-pairs/s", "ms_per_step": wbmax / args.steps * 1e3,
                               "us_per_structure": wbmax / args.steps / max(n_mine, 1) * 1e6, "roofline": roofline_of(nb, pb, ab, db)}
             if rank == 0:  # the host-inclusive path of the same shape: host arrays in, host pair lists out, packed launches (PCIe both ways)
@@ -323,25 +358,27 @@ def main():
                 keep_host = []
                 views = [aa.atoms_from_arrays(s, keep=keep_host) for s in soas]
                 arr = (C.POINTER(_lib.arp_atoms) * len(views))(*[C.pointer(v) for v in views])
-                c2 = aa.Context(dev_index)
-                handles = (C.c_void_p * 1)(c2._h)
+                c2, c3 = aa.Context(dev_index), aa.Context(dev_index)
                 host = {}
-                for name, only in (("contacts_only", True), ("all_candidates", False)):
+                for name, only, n_ctx in (("contacts_only", True, 1), ("all_candidates", False, 1), ("contacts_only_2ctx", True, 2), ("all_candidates_2ctx", False, 2)):
+                    # n_ctx = 2: two contexts on this one device stand in for two GPUs -- the in-process longest-first deal over devices, timed
+                    handles = (C.c_void_p * n_ctx)(*[c._h for c in (c2, c3)[:n_ctx]])
                     hp = aa.default_params(0.1, 6.5, contacts_only=only)
                     outs = (_lib.arp_pairs * len(views))()
                     best = None
                     for _ in range(3):
                         t0 = time.perf_counter()
-                        st = _lib.lib.arp_contacts_atomic_batch(handles, 1, arr, len(views), C.byref(hp), outs)
+                        st = _lib.lib.arp_contacts_atomic_batch(handles, n_ctx, arr, len(views), C.byref(hp), outs)
                         dt = time.perf_counter() - t0
                         assert st == 0, _lib.lib.arp_last_error()
                         n_out = sum(int(outs[k].n) for k in range(len(views)))
                         for k in range(len(views)):
                             _lib.lib.arp_pairs_free(C.byref(outs[k]))
                         best = dt if best is None else min(best, dt)
-                    host[name] = {"us_per_structure": best / len(views) * 1e6, "records_out": n_out}
+                    host[name] = {"us_per_structure": best / len(views) * 1e6, "records_out": n_out, "contexts": n_ctx}
                 sub["batch5k"]["host_path"] = {"structures": len(views), "note": "arp_contacts_atomic_batch: pageable host arrays in, host pair lists out "
-                                               "(PCIe both ways, never the `value`)", **host}
+                                               "(PCIe both ways, never the `value`); 16 distinct generated structures stand in for the 512; *_2ctx: two contexts on the one device",
+                                               **host}
 
     wall_max, pairs_all = reduce_job(dist, red_dev, wall, n_pairs)  # max over ranks / sum over ranks; no data-path collective
 
@@ -349,7 +386,7 @@ def main():
         # HBM traffic of the dominant kernel cannot be counted from inside this process; when the run matches the configuration
         # the committed rocprofv3 --pmc passes were taken on, report that measurement (profiles/, with its source), else null.
         traffic = None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tr = json.loads((ROOT / "profiles" / name).read_text())
                 if tr["workload"] == args.workload and tr["atoms"] == n_atoms and not args.deterministic and not args.contacts_only:
@@ -366,7 +403,7 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"{label}, groups='/', vdw_comp=0.1, dist_cutoff=6.5",
-                "atoms_per_gpu": n_atoms, "pairs_per_gpu": n_pairs, "sharding": "independent structures per rank, no collective",
+                "atoms_per_gpu": n_atoms, "pairs_per_gpu": n_pairs, "pairs_all_gpus": pairs_all, "sharding": "independent structures per rank, no collective",
                 "emitter": ("ordered two-pass" if args.deterministic else "single-pass") + (", contacts only (kind != 0)" if args.contacts_only else ""),
             },
             "roofline": roofline_of(n_atoms, n_pairs, acc, dev_ms, traffic),

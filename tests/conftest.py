@@ -30,3 +30,23 @@ def ubq_path():
 @pytest.fixture(scope="session")
 def bft_path():
     return str(DATA / "6bft.pdb")
+
+
+@pytest.fixture(scope="session")
+def c_consumer():
+    """tests/c_abi/consumer.c compiled as plain C11 against include/arpeggia_amd.h and linked to libarpeggia_amd.so: the compiled consumer
+    of the boundary (its _Static_asserts pin every field offset a #[repr(C)] binder hard-codes)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc on this machine")
+    out = ROOT / "tests" / "c_abi" / "build" / "consumer"
+    out.parent.mkdir(exist_ok=True)
+    lib_dir = ROOT / "arpeggia_amd"
+    cmd = [gcc, "-std=c11", "-Wall", "-Werror", "-O1", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c_abi" / "consumer.c"), "-o", str(out), f"-L{lib_dir}",
+           "-larpeggia_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return str(out)

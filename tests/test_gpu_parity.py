@@ -782,3 +782,16 @@ def test_no_ring_structure_is_an_error(ctx):
     with pytest.raises(aa.ArpeggiaError) as e:
         ctx.get_contacts(prod)
     assert e.value.status == _lib.ARP_ERR_NO_RINGS
+
+
+def test_compiled_c_consumer_runs_the_integration_sequence(c_consumer, ubq_path):
+    """INTEGRATION.md section 3 from a plain C program: load 1ubq -> arp_get_contacts -> columns -> Arrow C Data export -> release.  532 rows is
+    the count the reference's own test pins (python/tests/test_arpeggia.py:35), 20 columns its width (:67)."""
+    import subprocess
+
+    r = subprocess.run([c_consumer, ubq_path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1].startswith("532 rows"), r.stdout
+    cols = lines[0].split()[1:]
+    assert len(cols) == 20 and cols[0] == "model" and "interaction" in cols and "sc_centroid_angle" in cols

@@ -26,13 +26,27 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.arp_api_version() == 1
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(c_consumer):
+    """Field by field: the offsets and sizes a C compiler gives the header's structs (printed by the compiled consumer, whose own
+    _Static_asserts pin them to the numbers INTEGRATION.md's #[repr(C)] block assumes) against the ctypes mirror in _lib.py."""
     import ctypes as C
+    import json
+    import subprocess
 
-    assert C.sizeof(_lib.arp_pair) == 16
-    assert C.sizeof(_lib.arp_atoms) == 14 * 8 + 8
-    assert C.sizeof(_lib.arp_params) == 8 * (2 + 32 + 1) + 8
-    assert aa.PAIR_DTYPE.itemsize == 16
+    r = subprocess.run([c_consumer, "--abi"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    abi = json.loads(r.stdout)
+    assert abi["api_version"] == _lib.lib.arp_api_version() == 1
+    mirrors = {"arp_atoms": _lib.arp_atoms, "arp_params": _lib.arp_params, "arp_pair": _lib.arp_pair, "arp_pairs": _lib.arp_pairs, "arp_records": _lib.arp_records}
+    assert set(abi["structs"]) == set(mirrors)
+    for name, T in mirrors.items():
+        c = abi["structs"][name]
+        assert C.sizeof(T) == c["sizeof"], name
+        assert [f[0] for f in T._fields_] == list(c["fields"]), f"{name}: field order"
+        for fname, _ in [(f[0], f[1]) for f in T._fields_]:
+            d = getattr(T, fname)
+            assert [d.offset, d.size] == c["fields"][fname], f"{name}.{fname}"
+    assert aa.PAIR_DTYPE.itemsize == 16 and [aa.PAIR_DTYPE.fields[k][1] for k in ("i", "j", "dist", "kind")] == [0, 4, 8, 12]
 
 
 def test_interaction_vocabulary():
