@@ -1,5 +1,7 @@
 """Where the table path spends its time on a large structure (S1: ubiquitin copies on a lattice).  ARP_TIMING=1 prints the stages.
-Usage (GPU box): ARP_TIMING=1 python tests/table_scaling.py [n_atoms]"""
+Usage (GPU box): ARP_TIMING=1 python tests/table_scaling.py [n_atoms]
+The host-assembly rows (ARP_TABLE_HOST) only mean something with the TEST-ONLY library, which is the one that contains that code:
+ARPEGGIA_AMD_LIB=tests/hosttable/build/libarpeggia_amd_hosttable.so (arpeggia_amd/build.py build_host_table_library)."""
 import ctypes as C
 import os
 import sys

@@ -293,6 +293,22 @@ def test_full_size_properties_1e6(ctx):
     assert_pairs_equal(a, orc.atomic_contacts(), "s2 1e6")
 
 
+def test_s1_cloud_1e6_vs_oracle(ctx):
+    """The other half of BASELINE config 4 ("the headline run reports both"): the chemistry-faithful S1 cloud at 10^6 atoms, every pair against
+    the oracle -- indices and flags bit-exact, f32 distances bit-identical -- for both emitters and for the contacts-only filter."""
+    rec = synth.gen_s1(1_000_000, seed=0xA11CE5EED00 + 3)
+    prod = aa.Structure.from_records(rec, hierarchy=True)
+    soa = prod.soa("/")
+    want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True).atomic_contacts()
+    assert len(want) > 15_000_000
+    got = ctx.atomic_contacts(soa)
+    assert_pairs_equal(got, want, "s1 1e6")
+    only = ctx.atomic_contacts(soa, aa.default_params(contacts_only=True))
+    assert_pairs_equal(only, want[want["kind"] != 0], "s1 1e6 contacts only")
+    del got, only
+    assert_pairs_equal(ctx.atomic_contacts(soa, aa.default_params(deterministic=True)), want, "s1 1e6 ordered")
+
+
 # ---------------------------------------------------------------------------------------------- enqueue / batch forms
 def test_enqueue_with_resident_buffers_and_capacity_error(ctx):
     torch = pytest.importorskip("torch")
@@ -619,19 +635,32 @@ def test_device_planes_phe4_of_1ubq(ctx):
         assert min(np.abs(planes[r, 3:6] - pl["n"]).max(), np.abs(planes[r, 3:6] + pl["n"]).max()) < 1e-9
 
 
-def test_device_table_equals_the_host_assembly(ctx, monkeypatch):
+def table_cases():
+    return {"6bft": aa.load_model(str(synth.DATA / "6bft.pdb")), "stress_altlocs": aa.Structure.from_records(synth.gen_stress(n_res=300, seed=5, altlocs=True)),
+            "two_models": aa.Structure.from_records(synth.gen_stress(n_res=120, seed=9, n_models=2))}
+
+
+def test_device_table_equals_the_host_assembly(ctx):
     """The device table (plane fits, ring rows, sort, sc statistics as kernels) against the round-1 host assembly of the same pair
-    list, row for row: 6bft (17 CationPi + 43 pi rows), a stress structure with altlocs and insertion-free ties, two models."""
-    cases = [aa.load_model(str(synth.DATA / "6bft.pdb")), aa.Structure.from_records(synth.gen_stress(n_res=300, seed=5, altlocs=True)),
-             aa.Structure.from_records(synth.gen_stress(n_res=120, seed=9, n_models=2))]
-    for k, s in enumerate(cases):
+    list, row for row: 6bft (17 CationPi + 43 pi rows), a stress structure with altlocs and insertion-free ties, two models.  The host
+    assembly is not part of the product library: it lives in a test-only build (arpeggia_amd/build.py build_host_table_library) that a
+    child process loads."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from arpeggia_amd import build as B
+
+    lib = B.build_host_table_library()
+    env = dict(os.environ, ARPEGGIA_AMD_LIB=str(lib), ARP_TABLE_HOST="1")
+    r = subprocess.run([sys.executable, str(synth.DATA.parent / "hosttable" / "dump_table.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    host = json.loads(r.stdout.strip().splitlines()[-1])
+    for name, s in table_cases().items():
         for groups in ("/", "A,B/"):
             dev_rows = _table_lines(ctx.get_contacts(s, groups, 0.1, 6.5))
-            monkeypatch.setenv("ARP_TABLE_HOST", "1")
-            host_rows = _table_lines(ctx.get_contacts(s, groups, 0.1, 6.5))
-            monkeypatch.delenv("ARP_TABLE_HOST")
-            _lines_close(dev_rows, host_rows)
-            if k == 0 and groups == "/":
+            _lines_close(dev_rows, host[name][groups])
+            if name == "6bft" and groups == "/":
                 kinds = [ln.split(",")[1] for ln in dev_rows]
                 assert len(dev_rows) == 7236 and kinds.count("CationPi") == 17 and sum(x.startswith("Pi") for x in kinds) == 43
 
@@ -795,3 +824,12 @@ def test_compiled_c_consumer_runs_the_integration_sequence(c_consumer, ubq_path)
     assert lines[-1].startswith("532 rows"), r.stdout
     cols = lines[0].split()[1:]
     assert len(cols) == 20 and cols[0] == "model" and "interaction" in cols and "sc_centroid_angle" in cols
+
+
+def test_handwritten_mmcif_table_equals_the_pdb_twin_and_the_oracle(ctx):
+    """End to end from the hand-written deposition-layout mmCIF (tests/data/hand7.cif; see tests/test_host_cpu.py): its contact table equals
+    the table of the PDB twin, which equals the oracle's table row for row."""
+    want = ob.rows_to_csv_lines(ob.Structure.load(str(synth.DATA / "hand7.pdb")).get_contacts("/", 0.1, 6.5))
+    assert len(want) > 20
+    for ext in ("cif", "pdb"):
+        _lines_close(_table_lines(ctx.get_contacts(aa.load_model(str(synth.DATA / f"hand7.{ext}")), "/", 0.1, 6.5)), want)

@@ -252,3 +252,34 @@ def test_cli_writers(tmp_path):
     assert pq.read_table(tmp_path / "c.parquet").equals(t)
     assert json.loads((tmp_path / "c.json").read_text())[1]["sc_dihedral"] is None
     assert [json.loads(line)["interaction"] for line in (tmp_path / "c.ndjson").read_text().splitlines()] == ["VanDerWaalsContact", "PolarContact"]
+
+
+def test_handwritten_mmcif_in_deposition_layout_loads_like_its_pdb_twin():
+    """tests/data/hand7.cif is written by hand in the layout of a wwPDB deposition -- key-value categories, a semicolon text field that
+    contains `loop_` / `data_` / `_atom_site.id` as plain text, a quoted value with an embedded quote, both quote kinds around atom names,
+    `label_alt_id '.'`, `pdbx_PDB_ins_code '?'`, `label_seq_id '.'` on the waters, rows wrapped over two lines, a comment between two rows,
+    `pdbx_PDB_model_num` 1 and 2, and auth_* != label_* (chain X vs A / B, residues 101-106A vs 1-7) -- next to its PDB-format twin
+    hand7.pdb (MODEL / ENDMDL, altLoc, iCode, TER).  Nothing here comes from synth.write_mmcif.  Both must load to the same model, the one
+    the oracle's independent PDB reader builds (load_model, src/utils.rs:51-63: pdbtbx picks the author chain and numbering)."""
+    cif, pdb = aa.load_model(ROOT / "tests" / "data" / "hand7.cif"), aa.load_model(ROOT / "tests" / "data" / "hand7.pdb")
+    assert cif.n_atoms == pdb.n_atoms == 126
+    for col in ("chain", "resn", "atomn", "altloc", "insertion", "element"):
+        assert np.array_equal(cif.strings(col), pdb.strings(col)), col
+    for col in ("resi", "atomi", "model"):
+        assert np.array_equal(cif.ints(col), pdb.ints(col)), col
+    sa, sb = cif.soa("/"), pdb.soa("/")
+    assert sorted(sa) == sorted(sb) and all(np.array_equal(sa[k], sb[k]) for k in sa)
+    # what the file says, literally
+    assert set(cif.strings("chain")) == {b"X"}                                  # auth_asym_id, not label_asym_id A / B
+    resi, ins, alt, model = cif.ints("resi"), cif.strings("insertion"), cif.strings("altloc"), cif.ints("model")
+    assert sorted(set(resi)) == [101, 102, 103, 104, 105, 106, 201, 202, 203]   # auth_seq_id, not label_seq_id 1..7
+    thr = cif.strings("resn") == b"THR"
+    assert (resi[thr] == 106).all() and (ins[thr] == b"A").all() and (ins[~thr] == b"").all()
+    nz = (cif.strings("atomn") == b"NZ")
+    assert sorted(alt[nz & (model == 1)]) == [b"A", b"B"] and (alt[~nz] == b"").all()
+    assert sorted(set(model)) == [1, 2] and (model == 1).sum() == (model == 2).sum() == 63
+    assert np.allclose(sa["y"][model == 2] - sa["y"][model == 1], 0.25)
+    assert abs(sa["x"][0] - 27.340) < 1e-12 and abs(sa["z"][5] - 5.134) < 1e-12   # the wrapped row (atom 6) kept its coordinates
+    # and the oracle's own reader agrees on the PDB twin: hierarchy, ordinals, attribute words
+    _compare_structure(pdb, ob.Structure.load(str(ROOT / "tests" / "data" / "hand7.pdb")), "/")
+    _compare_structure(cif, ob.Structure.load(str(ROOT / "tests" / "data" / "hand7.pdb")), "/")

@@ -185,3 +185,31 @@ def test_angle_dihedral_helpers():
     assert abs(ob.dihedral([1, 0, 0], [0, 0, 0], [0, 0, 1], [0, 1, 1]) - 90.0) < 1e-12
     assert abs(ob.dihedral([1, 0, 0], [0, 0, 0], [0, 0, 1], [0, -1, 1]) - 90.0) < 1e-12
     assert abs(ob.dihedral([1, 0, 0], [0, 0, 0], [0, 0, 1], [1, 0, 1]) - 0.0) < 1e-6
+
+
+def test_sap_weight_reference_facts():
+    """The facts the reference's own tests hold about the SAP tables (src/sap.rs:362-376 test_hydrophobicity_values, :379-403
+    test_max_asa_values), asserted on the oracle's restatement AND on the product's arp_sap_weight (a host function: no GPU needed).
+    weight(resn, sasa) = hydrophobicity(resn) * clamp(sasa / max_sc_asa(resn), 0, 1)  (sap.rs:198-209), so a saturating sasa reads the
+    hydrophobicity and a small one the maximum side-chain ASA."""
+    import arpeggia_amd as aa
+
+    amino_acids = ["ALA", "ARG", "ASN", "ASP", "CYS", "GLU", "GLN", "GLY", "HIS", "ILE", "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL"]
+    for weight in (ob.sap_weight, aa.sap_weight):
+        hyd = {a: weight(a, 1e6) for a in amino_acids}           # sasa far above any maximum: the ratio clamps to 1
+        assert abs(hyd["GLY"] - 0.0) < 1e-6                        # sap.rs:364-365 glycine is the reference point
+        assert all(weight("GLY", s) == 0.0 for s in (0.0, 1.0, 50.0))
+        assert hyd["PHE"] > 0.4 and hyd["PHE"] == max(hyd.values())   # :367-369 "most hydrophobic"
+        assert hyd["ARG"] < -0.4 and hyd["ARG"] == min(hyd.values())  # :371-373 "most hydrophilic"
+        assert weight("XXX", 50.0) == 0.0                          # :375-376 unknown residue -> None -> contributes nothing (sap.rs:198-209)
+        max_asa = {}
+        for a in amino_acids:                                      # :381-394 every standard amino acid has a positive maximum side-chain ASA
+            if hyd[a] == 0.0:
+                continue                                           # (glycine's cannot be read through a zero weight)
+            w = weight(a, 1.0)
+            assert w != 0.0 and (w > 0) == (hyd[a] > 0), a
+            max_asa[a] = hyd[a] / w                                # 1 A^2 of SASA is below every maximum: ratio = 1 / max
+            assert 1.0 < max_asa[a] < 300.0, (a, max_asa[a])
+        assert len(max_asa) == 19
+        assert max_asa["TRP"] > max_asa["ALA"] and max_asa["TRP"] > 90.0   # :397-403 larger residues, larger maxima (TRP vs the small ones)
+        assert weight("PHE", -5.0) == 0.0                          # the ratio is clamped at 0 too
