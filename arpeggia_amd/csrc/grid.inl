@@ -10,7 +10,7 @@
 constexpr uint32_t kBoundsBlocks = 1024;
 
 DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, uint32_t n_models, uint32_t bad, GridParams *g, DevParams *prm,
-                      double cutoff, uint32_t ncells_cap) {
+                      double cutoff, uint32_t ncells_cap, uint32_t n_atoms) {
     double lo[3], ext[3];
     for (int k = 0; k < 3; k++) {
         lo[k] = empty ? 0.0 : lo_in[k];
@@ -26,14 +26,18 @@ DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, 
     // reference only ever uses cutoff^2, complex.rs:191, so a negative cutoff searches the same sphere)
     double edge = fabs(cutoff) * (1.0 + 1e-6);
     if (!(edge > 1e-3)) edge = 1e-3;
-    // cells kx = 4, 2 or 1 times finer along x, as the cell budget allows (arp_internal.h GridParams::kx)
+    // cells kx = 4, 2 or 1 times finer along x (arp_internal.h GridParams::kx): the finest split that keeps the cell count below about a
+    // third of the atom count.  Finer cells cut prefilter tests (S2 10^6 atoms: emit 188 / 177 / 174 us at kx = 1 / 2 / 4) but every cell
+    // is an entry of the count / scan / start arrays: a pack of 1250 five-thousand-atom structures, each model with its own slab of cells
+    // sized by the largest member, builds its grid in 340 / 393 / 455 us (profiles/r03_kx_sweep.txt).
     double nx, ny, nz;
-    uint32_t kx = 4u;
+    uint32_t kx = 1u;
+    const double soft_cap = fmin((double)ncells_cap, fmax(0.35 * (double)n_atoms, 4096.0));
     for (int it = 0;; ++it) {
         ny = floor(ext[1] / edge) + 1.0; nz = floor(ext[2] / edge) + 1.0;
         for (kx = 4u; kx > 1u; kx >>= 1) {
             nx = floor(ext[0] * (double)kx / edge) + 1.0;
-            if (nx * ny * (nz + 1.0) * (double)nm <= (double)ncells_cap) break;
+            if (nx * ny * (nz + 1.0) * (double)nm <= soft_cap) break;
         }
         nx = floor(ext[0] * (double)kx / edge) + 1.0;
         if (nx * ny * (nz + 1.0) * (double)nm <= (double)ncells_cap) break;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void k_model_bounds(DevAtoms in, uint32_t *box
 }
 
 __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t n_partials, GridParams *g, DevParams *prm, double cutoff,
-                                               uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr, const uint32_t *model_box, double *model_org) {
+                                               uint32_t ncells_cap, uint32_t n_atoms, unsigned long long *result, uint32_t *task_ctr, const uint32_t *model_box, double *model_org) {
     __shared__ double s_mn[4][3], s_mx[4][3];
     __shared__ uint32_t s_models[4], s_bad[4];
     for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
@@ -211,11 +215,11 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
         }
         if (threadIdx.x == 0) {
             const double zero[3] = {0.0, 0.0, 0.0}, hi[3] = {ext[0], ext[1], ext[2]};
-            grid_setup(zero, hi, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap);
+            grid_setup(zero, hi, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap, n_atoms);
             g->model_org = model_org;
         }
     } else if (threadIdx.x == 0) {
-        grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap);
+        grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap, n_atoms);
         g->model_org = nullptr;
     }
     if (threadIdx.x == 0) g->all_both = (acc.bad >> 24) & 1u ? 0u : 1u;

@@ -209,7 +209,7 @@ DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, double s, cons
 // Entry = the rows IonicBond / PolarContact / WeakPolarContact / IonicRepulsion / HydrophobicContact (complex.rs:238-296 without a
 // probe), bit 30 = "a donor..acceptor pair within 4.0 A" (hbond.rs:37,81: a hydrogen probe decides if a residue carries hydrogens),
 // bit 29 = CYS SG pair (vdw.rs:46-53: the dihedral probe decides inside the covalent band).
-DEVFN uint32_t pair_lut_entry(uint32_t idx) {
+__host__ __device__ constexpr inline uint32_t pair_lut_entry(uint32_t idx) {
     const uint32_t W = idx & 0x7Fu, L = idx >> 7;
     const uint32_t strong = W & 1u, weak = (W >> 1) & 1u, ion = (W >> 2) & 1u, rep = ((W >> 3) | (W >> 4)) & 1u, hy = (W >> 5) & 1u, sg = (W >> 6) & 1u;
     const uint32_t near45 = L >= 1u, near4 = L >= 2u, near35 = L >= 3u;

@@ -562,16 +562,23 @@ __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_li
         if (no_deferred_pass && result[3] != 0ull) result[1] |= 128ull;
     }
     if (P > tg.capacity || F != T) return;  // the caller's buffer cannot hold the table: report the size only
-    for (unsigned long long m = (unsigned long long)blockIdx.x * kFixThreads + i; m < F; m += (unsigned long long)gridDim.x * kFixThreads) {
-        uint32_t lo = 0, hi = kMaxHoles;  // last k with fpre[k] <= m (zero-length entries are skipped by taking the last one)
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (fpre[mid] <= m) lo = mid; else hi = mid; }
-        const unsigned long long dst = fstart[lo] + (m - fpre[lo]);
-        uint32_t lo2 = 0, hi2 = kMaxHoles;
-        while (hi2 - lo2 > 1) { const uint32_t mid = (lo2 + hi2) >> 1; if (tpre[mid] <= m) lo2 = mid; else hi2 = mid; }
-        const unsigned long long src = tail_start(lo2) + (m - tpre[lo2]);
-        uint4 *d = emit_slot(tg, dst, result);
-        const uint4 *sp = emit_slot(tg, src, result);
-        if (d && sp) *d = *sp;
+    // The copy, hole by hole: list entry e with a part of f = fpre[e + 1] - fpre[e] slots below P takes the records fpre[e] .. fpre[e] + f
+    // of the tail's valid stretches.  The block finds the tail chunk of the first one by ONE binary search (every thread the same LDS words:
+    // broadcast reads) and each thread walks on from there -- a hole is at most one chunk long, so it spans two or three stretches.  (One
+    // search per record and side, as before, was 22 dependent LDS reads per 16 bytes moved.)
+    for (uint32_t e = blockIdx.x; e < kMaxHoles; e += gridDim.x) {
+        const unsigned long long m0 = fpre[e], f = fpre[e + 1] - m0;
+        if (f == 0ull) continue;
+        uint32_t lo = 0, hi = kMaxHoles;  // last k with tpre[k] <= m0 (zero-length stretches are skipped by taking the last one)
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpre[mid] <= m0) lo = mid; else hi = mid; }
+        for (unsigned long long q = i; q < f; q += kFixThreads) {
+            const unsigned long long m = m0 + q;
+            uint32_t c = lo;
+            while (c + 1u < kMaxHoles && tpre[c + 1u] <= m) c++;
+            uint4 *d = emit_slot(tg, fstart[e] + q, result);
+            const uint4 *sp = emit_slot(tg, tail_start(c) + (m - tpre[c]), result);
+            if (d && sp) *d = *sp;
+        }
     }
 }
 
@@ -619,7 +626,7 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
         hipLaunchKernelGGL(k_model_box_init, dim3(65536u * 6u / 256u), dim3(256), 0, st, ws.model_box);
         hipLaunchKernelGGL(k_model_bounds, dim3(nb), dim3(256), 0, st, in, ws.model_box);
     }
-    hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, (const double *)ws.partials, bb, ws.grid, ws.params, cutoff, ws.ncells_cap, ws.result,
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, (const double *)ws.partials, bb, ws.grid, ws.params, cutoff, ws.ncells_cap, n, ws.result,
                        ws.task_ctr, in.per_model ? (const uint32_t *)ws.model_box : (const uint32_t *)nullptr, ws.model_org);
     P1();
     P0("grid_count");

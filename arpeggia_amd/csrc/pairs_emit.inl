@@ -39,7 +39,7 @@ struct WaveLdsE {
     unsigned long long hkey[64];              // ... and the chain key crm << 32 | res_ord
     uint32_t queue[kEQueue];                  // phase-1 survivors: home lane << 26 | neighbour slot
 };
-struct TablesE {                              // block-shared decision tables (14.3 KB)
+struct alignas(16) TablesE {                  // block-shared decision tables (14.3 KB)
     double s_clash[256], s_cov[256], s_vdw[256];   // bounds of the element pair (vdw.rs:32-43), index = class a << 4 | class b
     uint32_t lut[2048];                       // rows of a pair: index = W | Lg << 7 | Le << 9 (pair_lut2_entry)
 };
@@ -48,7 +48,7 @@ struct TablesE {                              // block-shared decision tables (1
 // level Le against the element pair's bounds {vdw, cov, clash} (both nested, so the level is a count).  Bits 0-18: the rows that need no
 // probe (complex.rs:217-296), bit 30: a hydrogen probe decides if either residue carries hydrogens (hbond.rs:37,81), bit 29: the
 // disulfide dihedral decides if residue tables were given (vdw.rs:46-53).  A steric clash ends the pair (complex.rs:233-235).
-DEVFN uint32_t pair_lut2_entry(uint32_t idx) {
+__host__ __device__ constexpr inline uint32_t pair_lut2_entry(uint32_t idx) {
     const uint32_t le = idx >> 9, base = pair_lut_entry(idx & 0x1FFu);
     if (le == 3u) return 1u << ARP_StericClash;
     uint32_t k = base & 0x1FFFFFFFu;
@@ -57,11 +57,21 @@ DEVFN uint32_t pair_lut2_entry(uint32_t idx) {
     k |= le == 2u ? (base & (1u << 29)) : 0u;
     return k;
 }
+// the table does not depend on the call: evaluated at compile time, it sits in the code object and a block copies it (8 KB out of L2)
+struct Lut2 { uint32_t v[2048]; };
+constexpr Lut2 make_lut2() {
+    Lut2 t{};
+    for (uint32_t k = 0; k < 2048u; k++) t.v[k] = pair_lut2_entry(k);
+    return t;
+}
+__device__ const Lut2 kLut2 = make_lut2();
 DEVFN void load_tables_e(TablesE &tb, const DevParams *dprm) {
     const double *src = dprm->s_clash;
     double *dst = tb.s_clash;
     for (uint32_t k = threadIdx.x; k < 3u * 256u; k += blockDim.x) dst[k] = src[k];
-    for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) tb.lut[k] = pair_lut2_entry(k);
+    const uint4 *lsrc = reinterpret_cast<const uint4 *>(kLut2.v);
+    uint4 *ldst = reinterpret_cast<uint4 *>(tb.lut);
+    for (uint32_t k = threadIdx.x; k < 512u; k += blockDim.x) ldst[k] = lsrc[k];
 }
 
 // Compaction rounds as one loop in assembly.  Every round, each lane with a surviving test (mask != 0) appends tag + (count of leading
