@@ -66,10 +66,29 @@ __global__ __launch_bounds__(256) void k_pack_fix(uint32_t n, uint32_t n_res, ui
 }
 
 // ---- split of the joint pair list: pairs per member, offsets, grouped copy with indices rebased to the member ----
+// A record's member = the member of its ligand atom i (members are contiguous atom ranges).  The emitter writes a batch's 64 records as one
+// run, and a batch comes from one task -- 64 consecutive slots of one model's slab -- so a wave's 64 records almost always share their
+// member: one descriptor search for the wave (first lane), a range check for the others, ONE atomic per wave.  (One 64-bit atomic per
+// record on a few hundred addresses was 10 ms per launch for a 12 M-record pack: most of the batch path's time with full candidate lists.)
+DEVFN uint32_t wave_owner(const PackDesc *desc, uint32_t K, uint32_t i, bool have, bool *uniform) {
+    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);  // (the first ACTIVE lane's: callers keep inactive lanes out by exec)
+    const uint32_t m0 = pack_owner(desc, K, i0, &PackDesc::first_atom);
+    const uint32_t lo = desc[m0].first_atom, hi = desc[m0 + 1u].first_atom;  // (desc has K + 1 entries: the sentinel holds the totals)
+    *uniform = __all(!have || (i >= lo && i < hi));
+    return m0;
+}
 __global__ __launch_bounds__(256) void k_split_count(const unsigned long long *result, const arp_pair *pairs, uint32_t K, const PackDesc *desc, unsigned long long *count) {
     const unsigned long long P = result[0];
-    for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(&count[pack_owner(desc, K, pairs[p].i, &PackDesc::first_atom)], 1ull);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (unsigned long long p0 = ((unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); p0 < P; p0 += (unsigned long long)gridDim.x * blockDim.x) {
+        const bool have = p0 + lane < P;
+        const uint32_t i = pairs[have ? p0 + lane : p0].i;
+        bool uniform;
+        const uint32_t m0 = wave_owner(desc, K, i, have, &uniform);
+        const unsigned long long vm = __ballot(have);  // (by the whole wave, not inside the one-lane branch)
+        if (uniform) { if (lane == 0) atomicAdd(&count[m0], (unsigned long long)__popcll(vm)); }
+        else if (have) atomicAdd(&count[pack_owner(desc, K, i, &PackDesc::first_atom)], 1ull);
+    }
 }
 // offset[m] = pairs of the members before m, offset[K] = P; cursor[m] = offset[m] (consumed by the scatter)
 __global__ __launch_bounds__(1024) void k_split_scan(uint32_t K, const unsigned long long *count, unsigned long long *offset, unsigned long long *cursor) {
@@ -93,11 +112,25 @@ __global__ __launch_bounds__(1024) void k_split_scan(uint32_t K, const unsigned 
 __global__ __launch_bounds__(256) void k_split_scatter(const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, uint32_t K, const PackDesc *desc,
                                                        unsigned long long *cursor) {
     const unsigned long long P = result[0];
-    for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (unsigned long long)gridDim.x * blockDim.x) {
-        arp_pair q = pairs[p];
-        const uint32_t m = pack_owner(desc, K, q.i, &PackDesc::first_atom), base = desc[m].first_atom;
-        q.i -= base; q.j -= base;
-        grouped[atomicAdd(&cursor[m], 1ull)] = q;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (unsigned long long p0 = ((unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); p0 < P; p0 += (unsigned long long)gridDim.x * blockDim.x) {
+        const bool have = p0 + lane < P;
+        arp_pair q = pairs[have ? p0 + lane : p0];
+        bool uniform;
+        const uint32_t m0 = wave_owner(desc, K, q.i, have, &uniform);
+        if (uniform) {  // the wave's records go to one member: one atomic, a coalesced run
+            const unsigned long long vm = __ballot(have);
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(&cursor[m0], (unsigned long long)__popcll(vm));
+            at = wave_first_u64(at);
+            const uint32_t base = desc[m0].first_atom;
+            q.i -= base; q.j -= base;
+            if (have) grouped[at + mbcnt(vm)] = q;
+        } else if (have) {
+            const uint32_t m = pack_owner(desc, K, q.i, &PackDesc::first_atom), base = desc[m].first_atom;
+            q.i -= base; q.j -= base;
+            grouped[atomicAdd(&cursor[m], 1ull)] = q;
+        }
     }
 }
 

@@ -10,11 +10,15 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <mutex>
+#include <new>
 #include <numeric>
 #include <string>
 #include <sys/mman.h>
 #include <system_error>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "arp_internal.h"
@@ -104,9 +108,8 @@ struct arp_context {
     char *bounce[2] = {nullptr, nullptr};   // pinned staging of large device -> host copies
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     uint64_t out_cap = 0;
-    arp_pair *grp_buf = nullptr;            // batch path: the pack's pair list grouped by member (device) ...
+    arp_pair *grp_buf = nullptr;            // batch path: the pack's pair list grouped by member (device); it lands in a SharedBlock on the host
     uint64_t grp_cap = 0;
-    char *out_pinned = nullptr;             // ... and its pinned landing block on the host
     unsigned long long *h_offsets = nullptr;  // pinned: per-member offsets into the grouped list (+ the pack status word)
     uint64_t h_offsets_cap = 0;
     DevParams *h_params = nullptr;         // pinned
@@ -234,7 +237,6 @@ extern "C" void arp_context_destroy(arp_context *ctx) {
     if (ctx->out_buf) (void)hipFree(ctx->out_buf);
     for (int k = 0; k < 2; k++) { if (ctx->scr_dev[k]) (void)hipFree(ctx->scr_dev[k]); if (ctx->scr_pin[k]) (void)hipHostFree(ctx->scr_pin[k]); }
     if (ctx->grp_buf) (void)hipFree(ctx->grp_buf);
-    if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
     if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
     for (int k = 0; k < 2; k++) { if (ctx->bounce[k]) (void)hipHostFree(ctx->bounce[k]); if (ctx->bounce_ev[k]) (void)hipEventDestroy(ctx->bounce_ev[k]); }
     if (ctx->h_params) (void)hipHostFree(ctx->h_params);
@@ -607,25 +609,72 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     return ARP_OK;
 }
 
+// ---- pair lists that share one pinned block (the batch path) --------------------------------------------------------------------
+// A pack's pair list crosses PCIe once, into ONE pinned block, and every member's arp_pairs is a view into it: no per-member malloc, no
+// second copy (70 KB of records per 5k-atom structure: the copies out of the landing block were most of the batch path's time with
+// full candidate lists).  The block is reference-counted through a registry keyed by the members' data pointers -- arp_pairs_free
+// finds it there -- and an idle block goes back to a pool instead of to the driver: pinning memory costs far more than the copy it saves.
+namespace {
+struct SharedBlock { char *pinned = nullptr; size_t cap = 0; long refs = 0; };
+std::mutex g_shared_mu;
+std::unordered_map<const void *, SharedBlock *> g_shared_views;
+std::vector<SharedBlock *> g_shared_pool;
+size_t g_shared_pool_bytes = 0;
+constexpr size_t kSharedPoolLimit = 6ull << 30;  // idle pinned memory kept for the next batch
+
+SharedBlock *shared_acquire(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_shared_mu);
+        size_t best = g_shared_pool.size();
+        for (size_t k = 0; k < g_shared_pool.size(); k++)
+            if (g_shared_pool[k]->cap >= bytes && (best == g_shared_pool.size() || g_shared_pool[k]->cap < g_shared_pool[best]->cap)) best = k;
+        if (best != g_shared_pool.size()) {
+            SharedBlock *b = g_shared_pool[best];
+            g_shared_pool.erase(g_shared_pool.begin() + (long)best);
+            g_shared_pool_bytes -= b->cap;
+            return b;
+        }
+    }
+    SharedBlock *b = new (std::nothrow) SharedBlock();
+    if (!b) return nullptr;
+    const size_t cap = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc((void **)&b->pinned, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); delete b; return nullptr; }
+    b->cap = cap;
+    return b;
+}
+void shared_release(SharedBlock *b) {  // (g_shared_mu held)
+    if (g_shared_pool_bytes + b->cap <= kSharedPoolLimit) { g_shared_pool.push_back(b); g_shared_pool_bytes += b->cap; return; }
+    (void)hipHostFree(b->pinned);
+    delete b;
+}
+}  // namespace
+
+std::shared_ptr<char> arp::pinned_block(size_t bytes) {
+    SharedBlock *b = shared_acquire(bytes);
+    if (!b) return nullptr;
+    return std::shared_ptr<char>(b->pinned, [b](char *) { std::lock_guard<std::mutex> lk(g_shared_mu); shared_release(b); });
+}
+
 extern "C" void arp_pairs_free(arp_pairs *pairs) {
     if (!pairs || !pairs->data) return;
     if (pairs->location == ARP_MEM_DEVICE) (void)hipFree(pairs->data);
-    else free(pairs->data);
+    else {
+        bool shared = false;
+        {
+            std::lock_guard<std::mutex> lk(g_shared_mu);
+            auto it = g_shared_views.find(pairs->data);
+            if (it != g_shared_views.end()) {
+                shared = true;
+                SharedBlock *b = it->second;
+                g_shared_views.erase(it);
+                if (--b->refs == 0) shared_release(b);
+            }
+        }
+        if (!shared) free(pairs->data);
+    }
     pairs->data = nullptr; pairs->n = 0;
 }
 
-// ---- batches of independent structures ---------------------------------------------------------------------------
-// the path shards over independent structures, no collective.  Structures are dealt longest-first to the
-// devices; each device runs ONE host thread that drives a two-deep pipeline of PACKS on two contexts (two streams, two
-// workspaces, two pinned staging blocks):
-//
-//   assemble pack i (helper threads copy the members' arrays, untouched, straight into the pinned block)
-//   -> one H2D copy -> renumber on the device (batch.inl) -> ONE launch sequence for the whole pack -> split the joint
-//   pair list into per-member lists on the device -> D2H of the grouped list -> helper threads hand out the members' lists
-//
-// While pack i is on the device, the host assembles pack i+1 and hands out pack i-1; the copies of one stream overlap the
-// kernels of the other.  Small structures do not fill the chip (a 5k-atom structure is ~80 wave tasks for 256 CUs, and the
-// nine launches of a call cost ~100 us whatever the size), which is why they share launches at all.
 namespace {
 constexpr uint64_t kPackAtoms = 1u << 20;    // atoms per pack: ~200 structures of 5k atoms; ~50 packs keep the pipeline full on a 10^4 batch
 constexpr uint32_t kPackMembers = 32768;     // members per pack (the device also checks that the models fit 16 bits)
@@ -693,12 +742,10 @@ arp_status ensure_pack_buffers(arp_context *ctx, uint64_t in_bytes, uint64_t out
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->out_buf) (void)hipFree(ctx->out_buf);
         if (ctx->grp_buf) (void)hipFree(ctx->grp_buf);
-        if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
-        ctx->out_buf = ctx->grp_buf = nullptr; ctx->out_pinned = nullptr; ctx->out_cap = ctx->grp_cap = 0;
+        ctx->out_buf = ctx->grp_buf = nullptr; ctx->out_cap = ctx->grp_cap = 0;
         HIP_TRY(hipMalloc((void **)&ctx->out_buf, out_records * sizeof(arp_pair)));
         ctx->out_cap = out_records;
         HIP_TRY(hipMalloc((void **)&ctx->grp_buf, out_records * sizeof(arp_pair)));
-        HIP_TRY(hipHostMalloc((void **)&ctx->out_pinned, out_records * sizeof(arp_pair), hipHostMallocDefault));
         ctx->grp_cap = out_records;
     }
     if (ctx->h_offsets_cap < K + 4) {
@@ -827,23 +874,31 @@ arp_status finalize_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp
         if ((s = ensure_pack_buffers(ctx, lay.total, total + total / 8, K)) != ARP_OK) return s;  // (the staged inputs stay where they are)
         if ((s = upload_params(ctx, params)) != ARP_OK || (s = enqueue_pack_kernels(sl, params)) != ARP_OK) return s;
     }
+    SharedBlock *blk = nullptr;
     if (total) {
-        HIP_TRY(hipMemcpyAsync(ctx->out_pinned, ctx->grp_buf, total * sizeof(arp_pair), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (!(blk = shared_acquire(total * sizeof(arp_pair)))) { set_error("out of pinned host memory for the batch's pair lists"); return ARP_ERR_OOM; }
+        hipError_t e = hipMemcpyAsync(blk->pinned, ctx->grp_buf, total * sizeof(arp_pair), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_shared_mu);
+            shared_release(blk);
+            set_error("HIP error %d (%s) copying the batch's pair lists to the host", (int)e, hipGetErrorString(e));
+            return ARP_ERR_HIP;
+        }
     }
     const unsigned long long *off = ctx->h_offsets;
-    const arp_pair *all = reinterpret_cast<const arp_pair *>(ctx->out_pinned);
-    std::atomic<bool> oom{false};
-    run_helpers(helpers, (size_t)K, [&](size_t m) {
+    std::lock_guard<std::mutex> lk(g_shared_mu);
+    for (uint64_t m = 0; m < K; m++) {  // every member's list is a view into the pack's block (arp_pairs_free drops the reference)
         arp_pairs &out = outs[pk.members[m]];
         const unsigned long long cnt = off[m + 1] - off[m];
         out.n = cnt; out.location = ARP_MEM_HOST; out.data = nullptr;
-        if (!cnt) return;
-        out.data = (arp_pair *)malloc(cnt * sizeof(arp_pair));
-        if (!out.data) { out.n = 0; oom = true; return; }
-        memcpy(out.data, all + off[m], cnt * sizeof(arp_pair));
-    });
-    if (oom) { set_error("out of host memory"); return ARP_ERR_OOM; }
+        if (!cnt) continue;
+        out.data = reinterpret_cast<arp_pair *>(blk->pinned) + off[m];
+        g_shared_views.emplace(out.data, blk);
+        blk->refs++;
+    }
+    if (blk && blk->refs == 0) shared_release(blk);
+    (void)helpers;
     return ARP_OK;
 }
 }  // namespace

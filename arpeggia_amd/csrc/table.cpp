@@ -273,8 +273,9 @@ struct arp_table {
     // device path: the table as it comes back -- rows of {from entity, to entity, distance, interaction} + side-chain statistics -- and the
     // entity book; the fixed-width columns below are materialised on first access (arp_table_column), the Arrow export reads rows + book
     std::shared_ptr<const EntityBook> book;
-    std::unique_ptr<TableRow[]> rows;
-    std::unique_ptr<TableSc[]> sc;
+    std::shared_ptr<char> rows_owner;          // the pooled pinned block (or heap block) rows and sc live in
+    const TableRow *rows = nullptr;
+    const TableSc *sc = nullptr;
     std::once_flag columns_once;
     std::vector<uint32_t> model;
     std::vector<int32_t> interaction, from_resi, from_atomi, to_resi, to_atomi, from_atom, to_atom;
@@ -571,7 +572,7 @@ arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *g
     // the table keeps the rows as they came back and a reference to the structure's entity book: no per-row host work here
     arp_table *t = new arp_table();
     t->n = rows.n;
-    t->rows = std::move(rows.rows); t->sc = std::move(rows.sc);
+    t->rows_owner = std::move(rows.owner); t->rows = rows.rows; t->sc = rows.sc;
     t->book = c->book;
     lap("table object");
     *out = t;

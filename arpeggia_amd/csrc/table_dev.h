@@ -48,11 +48,15 @@ struct DevStructure {
 
 struct TableRow { uint32_t from_ent, to_ent; float distance; int32_t interaction; };   // entity = atom index, or n_atoms + ring index
 struct TableSc { float dist, dihedral, angle, valid; };                                   // valid != 0: both residues have a side-chain plane
-struct TableRowsHost {   // what comes back: rows in final order (plain arrays: no zero fill of a million rows)
+// What comes back: rows in final order.  A large table lands straight in a pooled pinned block (engine.cpp pinned_block) that the table
+// then OWNS -- no copy out of a landing buffer; a small one is copied into plain arrays.  `owner` keeps whichever it is alive.
+struct TableRowsHost {
     uint64_t n = 0;
-    std::unique_ptr<TableRow[]> rows;
-    std::unique_ptr<TableSc[]> sc;
+    std::shared_ptr<char> owner;
+    TableRow *rows = nullptr;
+    TableSc *sc = nullptr;
 };
+std::shared_ptr<char> pinned_block(size_t bytes);   // pooled pinned host memory; the deleter gives the block back to the pool (engine.cpp)
 
 // Runs the whole device pipeline for one structure.  `pairs_dev` = contacts-only pair list on the device (arp_contacts_atomic,
 // ARP_MEM_DEVICE).  Returns ARP_ERR_NO_RINGS etc. like arp_get_contacts.

@@ -509,44 +509,32 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         TRY_HIP(hipGetLastError());
         lap("sort+finish");
     }
-    // Rows and sc values come back in kParts pieces: while piece k+1 crosses PCIe the host copies piece k out of the pinned block into the
-    // table's own arrays -- which it allocated and touched while the device was still sorting.
-    constexpr int kMaxParts = 4;
-    const int kParts = n_rows > (1u << 18) ? kMaxParts : 1;   // (a small table: one copy, no events -- the pieces cost more than they hide)
-    hipEvent_t ev[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
-    const char *src_rows = pin, *src_sc = pin + al((uint64_t)rows_cap * 16);
-    auto part_lo = [&](int k) { return (size_t)((uint64_t)n_rows * (uint64_t)k / kParts); };
-    hipError_t ce = hipSuccess;
-    for (int k = 0; k < kParts && n_rows && ce == hipSuccess; k++) {
-        const size_t a0 = part_lo(k), a1 = part_lo(k + 1);
-        if (a1 > a0) {
-            ce = hipMemcpyAsync(pin + a0 * 16, out_rows + a0, (a1 - a0) * 16, hipMemcpyDeviceToHost, st);
-            if (ce == hipSuccess) ce = hipMemcpyAsync(pin + al((uint64_t)rows_cap * 16) + a0 * 16, out_sc + a0, (a1 - a0) * 16, hipMemcpyDeviceToHost, st);
-        }
-        if (kParts > 1 && ce == hipSuccess) ce = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
-        if (kParts > 1 && ce == hipSuccess) ce = hipEventRecord(ev[k], st);
-    }
+    // Rows and sc values come back in ONE copy each.  A large table lands in a pooled pinned block that the table object then owns (the
+    // Arrow export and the column accessors read it in place); a small one goes through the context's landing buffer into plain arrays.
     out->n = n_rows;
-    out->rows.reset(new TableRow[n_rows ? n_rows : 1]);
-    out->sc.reset(new TableSc[n_rows ? n_rows : 1]);
-    if (kParts > 1) parallel_for((size_t)n_rows * 2, 1u << 16, [&](size_t k0, size_t k1, size_t) {  // first touch of the fresh pages, off the critical path
-        char *base0 = (char *)out->rows.get(), *base1 = (char *)out->sc.get();
-        for (size_t k = k0; k < k1; k += 256) { if (k < n_rows) base0[k * 16] = 0; else base1[(k - n_rows) * 16] = 0; }
-    });
-    for (int k = 0; k < kParts && n_rows; k++) {
-        if (ce == hipSuccess) ce = ev[k] ? hipEventSynchronize(ev[k]) : hipStreamSynchronize(st);
-        if (ce != hipSuccess) break;
-        const size_t a0 = part_lo(k), a1 = part_lo(k + 1), nk = a1 - a0;
-        parallel_for(nk * 2, 1u << 16, [&](size_t k0, size_t k1, size_t) {  // two 16-byte arrays, copied in slices by the host workers
-            const size_t r0 = std::min<size_t>(k0, nk), r1 = std::min<size_t>(k1, nk);
-            if (r1 > r0) memcpy(out->rows.get() + a0 + r0, src_rows + (a0 + r0) * 16, (r1 - r0) * 16);
-            const size_t b0 = std::max<size_t>(k0, nk) - nk, b1 = std::max<size_t>(k1, nk) - nk;
-            if (b1 > b0) memcpy(out->sc.get() + a0 + b0, src_sc + (a0 + b0) * 16, (b1 - b0) * 16);
-        });
+    const size_t row_bytes = (size_t)n_rows * 16;
+    if (row_bytes >= (1u << 20)) {
+        out->owner = pinned_block(2 * al(row_bytes));
+        if (!out->owner) { set_error("out of pinned host memory for the table"); return ARP_ERR_OOM; }
+        out->rows = reinterpret_cast<TableRow *>(out->owner.get());
+        out->sc = reinterpret_cast<TableSc *>(out->owner.get() + al(row_bytes));
+        TRY_HIP(hipMemcpyAsync(out->rows, out_rows, row_bytes, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipMemcpyAsync(out->sc, out_sc, row_bytes, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipStreamSynchronize(st));
+    } else {
+        char *heap = (char *)malloc(2 * al(row_bytes) + 64);
+        if (!heap) { set_error("out of host memory"); return ARP_ERR_OOM; }
+        out->owner = std::shared_ptr<char>(heap, [](char *q) { free(q); });
+        out->rows = reinterpret_cast<TableRow *>(heap);
+        out->sc = reinterpret_cast<TableSc *>(heap + al(row_bytes));
+        if (n_rows) {
+            TRY_HIP(hipMemcpyAsync(pin, out_rows, row_bytes, hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipMemcpyAsync(pin + al((uint64_t)rows_cap * 16), out_sc, row_bytes, hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipStreamSynchronize(st));
+            memcpy(out->rows, pin, row_bytes);
+            memcpy(out->sc, pin + al((uint64_t)rows_cap * 16), row_bytes);
+        }
     }
-    for (int k = 0; k < kMaxParts; k++) if (ev[k]) (void)hipEventDestroy(ev[k]);
-    if (ce != hipSuccess) { set_error("HIP error %d (%s) while copying the table back", (int)ce, hipGetErrorString(ce)); return ARP_ERR_HIP; }
-    TRY_HIP(hipStreamSynchronize(st));
     lap("unpack");
     return ARP_OK;
 }

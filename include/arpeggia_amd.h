@@ -156,7 +156,9 @@ arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs);
 /* Batch of independent structures sharded over devices (no collective).  ctxs[d] is a context on
  * device d; structure k goes to a device by longest-processing-time-first on its atom count; one host thread
  * per device; with ARP_FLAG_CONTACTS_ONLY small structures of a device's share are packed into shared launches.
- * outs[k] is filled like arp_contacts_atomic (host memory). */
+ * outs[k] is filled like arp_contacts_atomic (host memory).  The lists of structures that shared a pack are views into ONE pinned block
+ * (one PCIe copy per pack, no copy per member): release every outs[k] with arp_pairs_free as usual -- the block is reference-counted and
+ * goes back to a pool when its last list is freed; do not free() the pointers yourself. */
 arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms,
                                      int32_t n_structures, const arp_params *params, arp_pairs *outs);
 
