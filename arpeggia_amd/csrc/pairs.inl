@@ -562,23 +562,37 @@ __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_li
         if (no_deferred_pass && result[3] != 0ull) result[1] |= 128ull;
     }
     if (P > tg.capacity || F != T) return;  // the caller's buffer cannot hold the table: report the size only
-    // The copy, hole by hole: list entry e with a part of f = fpre[e + 1] - fpre[e] slots below P takes the records fpre[e] .. fpre[e] + f
-    // of the tail's valid stretches.  The block finds the tail chunk of the first one by ONE binary search (every thread the same LDS words:
-    // broadcast reads) and each thread walks on from there -- a hole is at most one chunk long, so it spans two or three stretches.  (One
-    // search per record and side, as before, was 22 dependent LDS reads per 16 bytes moved.)
-    for (uint32_t e = blockIdx.x; e < kMaxHoles; e += gridDim.x) {
-        const unsigned long long m0 = fpre[e], f = fpre[e + 1] - m0;
-        if (f == 0ull) continue;
+    // The copy.  List entry e with a part of f = fpre[e + 1] - fpre[e] slots below P takes the records fpre[e] .. fpre[e] + f of the tail's
+    // valid stretches.  A block owns the entries e = blockIdx.x + j * gridDim.x (j < kFixPer: two or three real holes of a 4096-record
+    // chunk at most); wave j finds the tail chunk of entry j's first record by ONE binary search (every lane the same LDS words: broadcast
+    // reads), then all threads run over the block's slots as ONE flat index space -- every iteration independent, so the loads of a
+    // thread's six or so records are in flight together (hole after hole, each copy waited for the previous hole's round trip to memory).
+    constexpr uint32_t kFixPer = kMaxHoles / 256u;
+    __shared__ unsigned long long b_m0[kFixPer], b_pre[kFixPer + 1], b_dst[kFixPer];
+    __shared__ uint32_t b_chunk[kFixPer];
+    if (gridDim.x * kFixPer < kMaxHoles) return;  // (launched with 256 blocks)
+    const uint32_t wv = i >> 6;
+    if (wv < kFixPer) {
+        const uint32_t e = blockIdx.x + wv * gridDim.x;
+        const unsigned long long m0 = fpre[e];
         uint32_t lo = 0, hi = kMaxHoles;  // last k with tpre[k] <= m0 (zero-length stretches are skipped by taking the last one)
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpre[mid] <= m0) lo = mid; else hi = mid; }
-        for (unsigned long long q = i; q < f; q += kFixThreads) {
-            const unsigned long long m = m0 + q;
-            uint32_t c = lo;
-            while (c + 1u < kMaxHoles && tpre[c + 1u] <= m) c++;
-            uint4 *d = emit_slot(tg, fstart[e] + q, result);
-            const uint4 *sp = emit_slot(tg, tail_start(c) + (m - tpre[c]), result);
-            if (d && sp) *d = *sp;
-        }
+        if ((i & 63u) == 0u) { b_m0[wv] = m0; b_dst[wv] = fstart[e]; b_chunk[wv] = lo; b_pre[wv + 1] = fpre[e + 1] - m0; }
+    }
+    __syncthreads();
+    if (i == 0) { unsigned long long run = 0; b_pre[0] = 0; for (uint32_t j = 0; j < kFixPer; j++) { run += b_pre[j + 1]; b_pre[j + 1] = run; } }
+    __syncthreads();
+    const unsigned long long total = b_pre[kFixPer];
+    for (unsigned long long q = i; q < total; q += kFixThreads) {
+        uint32_t j = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < kFixPer; k++) j += (b_pre[k] <= q) ? 1u : 0u;  // (b_pre is non-decreasing: the count is the index)
+        const unsigned long long r = q - b_pre[j], m = b_m0[j] + r;
+        uint32_t c = b_chunk[j];
+        while (c + 1u < kMaxHoles && tpre[c + 1u] <= m) c++;
+        uint4 *d = emit_slot(tg, b_dst[j] + r, result);
+        const uint4 *sp = emit_slot(tg, tail_start(c) + (m - tpre[c]), result);
+        if (d && sp) *d = *sp;
     }
 }
 

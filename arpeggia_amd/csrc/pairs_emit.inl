@@ -125,6 +125,7 @@ ARP_LMASK_CMP(lm_ge_f64_sv, "v_cmp_ge_f64_e32", double, "s", double, "v")      /
 ARP_LMASK_CMP(lm_lt_u32_sv, "v_cmp_lt_u32_e32", uint32_t, "s", uint32_t, "v")  // a (scalar) <  b
 ARP_LMASK_CMP(lm_gt_u32_sv, "v_cmp_gt_u32_e32", uint32_t, "s", uint32_t, "v")  // a (scalar) >  b
 ARP_LMASK_CMP(lm_ne_u32, "v_cmp_ne_u32_e32", uint32_t, "v", uint32_t, "v")
+ARP_LMASK_CMP(lm_lt_u32_vv, "v_cmp_lt_u32_e32", uint32_t, "v", uint32_t, "v")  // a < b
 ARP_LMASK_CMP(lm_lt_u64, "v_cmp_lt_u64_e32", unsigned long long, "v", unsigned long long, "v")
 #undef ARP_LMASK_CMP
 DEVFN uint32_t lm_select(lmask m, uint32_t if_set, uint32_t if_clear) {
@@ -176,12 +177,19 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
         const uint32_t d1 = (uint32_t)kb - (uint32_t)ka + 1u;                   // residue ordinals of one chain: |difference| >= 2 (:113)
         m_ok = lm_lt_u32_sv(2u, d1) | lm_ne_u32((uint32_t)(ka >> 32), (uint32_t)(kb >> 32));  // another chain: always (:124-129); models never meet in the grid
         m_swap = lm_lt_u64(kb, ka);
-    } else {
-        Fat fa, fb;
-        fa.pw = pa; fa.res_ord = (uint32_t)ka; fa.crm = (uint32_t)(ka >> 32);
-        fb.pw = pb; fb.res_ord = (uint32_t)kb; fb.crm = (uint32_t)(kb >> 32);
-        const int o = orient(fa, fb);
-        m_ok = __ballot(o != 0); m_swap = __ballot(o == 2);
+    } else {  // chain groups: orient() of kernels.hip on lane masks (every comparison lands in a scalar register pair)
+        const uint32_t ca = (uint32_t)(ka >> 32) & 0xFFFFu, cb = (uint32_t)(kb >> 32) & 0xFFFFu;
+        const lmask same_model = ~lm_lt_u32_sv(0xFFFFu, (uint32_t)(ka >> 32) ^ (uint32_t)(kb >> 32));       // :96-98
+        const lmask same_chain = ~lm_ne_u32(ca, cb);
+        const lmask ab_chain = lm_lt_u32_vv((uint32_t)ka + 1u, (uint32_t)kb), ba_chain = lm_lt_u32_vv((uint32_t)kb + 1u, (uint32_t)ka);  // :108,:113
+        const uint32_t lr = pa & pb;                                                                            // bit 24: both ligand, bit 25: both receptor
+        const lmask both = lm_lt_u32_sv(0u, lr & (lr >> 1) & kPwLigand);                                        // :124-129
+        const lmask ab_cross = ~(both & lm_lt_u32_vv(cb, ca)), ba_cross = ~(both & lm_lt_u32_vv(ca, cb));
+        const lmask aL = lm_lt_u32_sv(0u, pa & kPwLigand), aR = lm_lt_u32_sv(0u, pa & kPwReceptor);
+        const lmask bL = lm_lt_u32_sv(0u, pb & kPwLigand), bR = lm_lt_u32_sv(0u, pb & kPwReceptor);
+        const lmask o1 = same_model & aL & bR & ((same_chain & ab_chain) | (~same_chain & ab_cross));
+        const lmask o2 = same_model & bL & aR & ((same_chain & ba_chain) | (~same_chain & ba_cross));
+        m_ok = o1 | o2; m_swap = o2 & ~o1;
     }
     lmask m_valid = m_act & lm_ge_f64_sv(K.r2, s) & m_ok;  // rstar: inclusive
     const uint32_t n_early = ONLY ? 0u : (uint32_t)__popcll(m_valid);
