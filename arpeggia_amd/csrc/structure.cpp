@@ -125,10 +125,6 @@ struct Record {
     uint32_t res_ord, res_id;  // hierarchy == 1 only
 };
 
-static void put(char *dst, size_t cap, const std::string &s) {
-    memset(dst, 0, cap);
-    memcpy(dst, s.data(), std::min(cap - 1, s.size()));
-}
 
 // Fixed-column fields straight out of the file buffer (no per-field std::string: a 10k-atom file has 130k fields).
 struct Field { const char *b, *e; };  // trimmed [b, e)
