@@ -15,4 +15,4 @@ find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -12
 timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tests/batch_timing.py 2048 trace > $OUT/trace.log 2>&1
 python3 $GRAFT_REPO_ROOT/tests/trace_overlap.py $OUT/trace > $OUT/batch_overlap.txt 2>&1; cat $OUT/batch_overlap.txt
 rm -rf $OUT/trace/*/*kernel_trace.csv $OUT/trace/*/*memory_copy_trace.csv 2>/dev/null
-cd $GRAFT_REPO_ROOT && bash tests/run_gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary.txt; grep -A8 "k_pairs<2, false>" $OUT/pmc_summary.txt | head -10
+cd $GRAFT_REPO_ROOT && bash tests/run_gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary.txt; grep -A30 "k_emit<12, 1, false>" $OUT/pmc_summary.txt | head -32
