@@ -12,11 +12,27 @@ DEVFN uint32_t pack_owner(const PackDesc *desc, uint32_t K, uint32_t v, uint32_t
     return lo;
 }
 
+// (members are contiguous atom ranges: a wave of consecutive atoms, or of records of one emitter batch, is almost always inside one)
+struct OwnerCache { uint32_t m = 0, lo = 1, hi = 0; };  // (wave-uniform) the member the wave saw last and its atom range
+// member of every lane's atom; lanes without a record get ARP_NONE
+DEVFN uint32_t lane_owner(const PackDesc *desc, uint32_t K, uint32_t i, bool have, OwnerCache &c) {
+    if (!__any(have)) return ARP_NONE;
+    if (!__all(!have || (i >= c.lo && i < c.hi))) {
+        const unsigned long long vm = __ballot(have);
+        const uint32_t i0 = (uint32_t)__shfl((int)i, (int)__ffsll((long long)vm) - 1);
+        c.m = pack_owner(desc, K, i0, &PackDesc::first_atom);
+        c.lo = desc[c.m].first_atom; c.hi = desc[c.m + 1u].first_atom;  // (desc has K + 1 entries: the sentinel holds the totals)
+    }
+    if (!have) return ARP_NONE;
+    return (i >= c.lo && i < c.hi) ? c.m : pack_owner(desc, K, i, &PackDesc::first_atom);
+}
 // models per member (max ordinal + 1): one atomic per run of same-owner atoms in a wave (members are contiguous)
 __global__ __launch_bounds__(256) void k_pack_models(uint32_t n, uint32_t K, const PackDesc *desc, const uint16_t *model, uint32_t *n_models) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     uint32_t own = ARP_NONE, m = 0;
-    if (i < n) { own = pack_owner(desc, K, i, &PackDesc::first_atom); m = (uint32_t)model[i] + 1u; }
+    OwnerCache oc;
+    own = lane_owner(desc, K, i, i < n, oc);
+    if (i < n) m = (uint32_t)model[i] + 1u;
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)own);
     if (__all(own == first || own == ARP_NONE)) {  // the common case: the whole wave belongs to one member
         const uint32_t mx = wave_max_u32(own == ARP_NONE ? 0u : m);
@@ -50,8 +66,10 @@ __global__ __launch_bounds__(1024) void k_pack_scan(uint32_t K, const uint32_t *
 __global__ __launch_bounds__(256) void k_pack_fix(uint32_t n, uint32_t n_res, uint32_t n_h, uint32_t K, const PackDesc *desc, uint16_t *model, uint32_t *res_id,
                                                   uint32_t *res_h_ptr, uint32_t *res_cb, uint32_t *res_sg, uint32_t *res_h_idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    OwnerCache oc;
+    const uint32_t own = lane_owner(desc, K, i, i < n, oc);
     if (i < n) {
-        const PackDesc d = desc[pack_owner(desc, K, i, &PackDesc::first_atom)];
+        const PackDesc d = desc[own];
         model[i] = (uint16_t)(model[i] + d.model_off);
         res_id[i] += d.first_res;
     }
@@ -66,29 +84,43 @@ __global__ __launch_bounds__(256) void k_pack_fix(uint32_t n, uint32_t n_res, ui
 }
 
 // ---- split of the joint pair list: pairs per member, offsets, grouped copy with indices rebased to the member ----
-// A record's member = the member of its ligand atom i (members are contiguous atom ranges).  The emitter writes a batch's 64 records as one
-// run, and a batch comes from one task -- 64 consecutive slots of one model's slab -- so a wave's 64 records almost always share their
-// member: one descriptor search for the wave (first lane), a range check for the others, ONE atomic per wave.  (One 64-bit atomic per
-// record on a few hundred addresses was 10 ms per launch for a 12 M-record pack: most of the batch path's time with full candidate lists.)
-DEVFN uint32_t wave_owner(const PackDesc *desc, uint32_t K, uint32_t i, bool have, bool *uniform) {
-    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);  // (the first ACTIVE lane's: callers keep inactive lanes out by exec)
-    const uint32_t m0 = pack_owner(desc, K, i0, &PackDesc::first_atom);
-    const uint32_t lo = desc[m0].first_atom, hi = desc[m0 + 1u].first_atom;  // (desc has K + 1 entries: the sentinel holds the totals)
-    *uniform = __all(!have || (i >= lo && i < hi));
-    return m0;
+// A record's member = the member of its ligand atom i (members are contiguous atom ranges).  Both kernels below give every wave ONE
+// CONTIGUOUS range of the list.  The emitter writes a batch's 64 records as one run and a batch comes from one task -- 64 consecutive
+// slots of one model's slab -- so a range of a few thousand records mentions a handful of members: a wave adds up its records per member
+// first and touches the members' counters once per (wave, member).  Same-address device atomics serialise at ~11 ns each; one per
+// 64 records, with a thousand waves on the same three or four members at any moment, made each of these kernels 7-13 ms per
+// 14 M-record pack, i.e. nearly all of the batch path's time with full candidate lists.
+constexpr uint32_t kSplitBlocks = 1024, kSplitThreads = 256, kSplitSlots = 8;
+
+DEVFN void split_range(unsigned long long P, unsigned long long *lo, unsigned long long *hi) {  // this wave's records
+    const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
+    const unsigned long long per = (((P + waves - 1ull) / waves) + 63ull) & ~63ull;
+    const unsigned long long w = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+    *lo = min(P, w * per); *hi = min(P, *lo + per);
 }
-__global__ __launch_bounds__(256) void k_split_count(const unsigned long long *result, const arp_pair *pairs, uint32_t K, const PackDesc *desc, unsigned long long *count) {
+
+__global__ __launch_bounds__(kSplitThreads) void k_split_count(const unsigned long long *result, const arp_pair *pairs, uint32_t K, const PackDesc *desc, unsigned long long *count) {
     const unsigned long long P = result[0];
     const uint32_t lane = threadIdx.x & 63u;
-    for (unsigned long long p0 = ((unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); p0 < P; p0 += (unsigned long long)gridDim.x * blockDim.x) {
-        const bool have = p0 + lane < P;
-        const uint32_t i = pairs[have ? p0 + lane : p0].i;
-        bool uniform;
-        const uint32_t m0 = wave_owner(desc, K, i, have, &uniform);
-        const unsigned long long vm = __ballot(have);  // (by the whole wave, not inside the one-lane branch)
-        if (uniform) { if (lane == 0) atomicAdd(&count[m0], (unsigned long long)__popcll(vm)); }
-        else if (have) atomicAdd(&count[pack_owner(desc, K, i, &PackDesc::first_atom)], 1ull);
+    unsigned long long lo, hi;
+    split_range(P, &lo, &hi);
+    OwnerCache oc;
+    uint32_t cur = ARP_NONE, cnt = 0;  // (wave-uniform) the run of records of one member being added up
+    for (unsigned long long p0 = lo; p0 < hi; p0 += 64u) {
+        const bool have = p0 + lane < hi;
+        const uint32_t m = lane_owner(desc, K, pairs[have ? p0 + lane : p0].i, have, oc);
+        for (unsigned long long rem = __ballot(have); rem;) {  // the distinct members of these 64 records (almost always one)
+            const uint32_t mm = (uint32_t)__shfl((int)m, (int)__ffsll((long long)rem) - 1);
+            const unsigned long long mask = __ballot(have && m == mm);
+            if (mm != cur) {
+                if (cnt && lane == 0) atomicAdd(&count[cur], (unsigned long long)cnt);
+                cur = mm; cnt = 0;
+            }
+            cnt += (uint32_t)__popcll(mask);
+            rem &= ~mask;
+        }
     }
+    if (cnt && lane == 0) atomicAdd(&count[cur], (unsigned long long)cnt);
 }
 // offset[m] = pairs of the members before m, offset[K] = P; cursor[m] = offset[m] (consumed by the scatter)
 __global__ __launch_bounds__(1024) void k_split_scan(uint32_t K, const unsigned long long *count, unsigned long long *offset, unsigned long long *cursor) {
@@ -107,29 +139,76 @@ __global__ __launch_bounds__(1024) void k_split_scan(uint32_t K, const unsigned 
     unsigned long long run = part[threadIdx.x];
     for (uint32_t m = lo; m < hi; m++) { offset[m] = run; cursor[m] = run; run += count[m]; }
 }
-// The single-pass emitter's list is in no particular order: every record takes the next free place of its member.  (The ordered
-// emitter is not packed: its list is laid out task by task, and a task that straddles two members interleaves their records.)
-__global__ __launch_bounds__(256) void k_split_scatter(const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, uint32_t K, const PackDesc *desc,
-                                                       unsigned long long *cursor) {
+// The single-pass emitter's list is in no particular order: a member's records land in its part of the grouped list in whatever order
+// the waves reserve their places.  (The ordered emitter is not packed: its list is laid out task by task, and a task that straddles two
+// members interleaves their records.)  A wave first adds up its range per member in a table of kSplitSlots entries, reserves each
+// member's places with ONE atomic, then copies; if its range mentions more members than the table holds (packs of tiny structures), the
+// rest of the range reserves per 64 records.
+struct SplitTable { uint32_t member[kSplitSlots], count[kSplitSlots], run[kSplitSlots]; unsigned long long base[kSplitSlots]; };
+__global__ __launch_bounds__(kSplitThreads) void k_split_scatter(const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, uint32_t K, const PackDesc *desc,
+                                                                unsigned long long *cursor) {
+    __shared__ SplitTable tables[kSplitThreads / 64];
+    SplitTable &t = tables[threadIdx.x >> 6];  // (private to the wave: its lanes run in lockstep, LDS operations of one wave stay in order)
     const unsigned long long P = result[0];
     const uint32_t lane = threadIdx.x & 63u;
-    for (unsigned long long p0 = ((unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); p0 < P; p0 += (unsigned long long)gridDim.x * blockDim.x) {
-        const bool have = p0 + lane < P;
+    unsigned long long lo, hi;
+    split_range(P, &lo, &hi);
+    OwnerCache oc;
+    uint32_t n_ent = 0;                     // (wave-uniform)
+    unsigned long long tabled_end = hi;     // records before this one are in the table
+    auto find = [&](uint32_t mm) { uint32_t e = 0; while (e < n_ent && t.member[e] != mm) e++; return e; };
+    for (unsigned long long p0 = lo; p0 < hi; p0 += 64u) {
+        const bool have = p0 + lane < hi;
+        const uint32_t m = lane_owner(desc, K, pairs[have ? p0 + lane : p0].i, have, oc);
+        bool fits = true;
+        for (unsigned long long rem = __ballot(have); rem;) {  // every member of these 64 records needs an entry before any is counted
+            const uint32_t mm = (uint32_t)__shfl((int)m, (int)__ffsll((long long)rem) - 1);
+            rem &= ~__ballot(have && m == mm);
+            if (find(mm) < n_ent) continue;
+            if (n_ent == kSplitSlots) { fits = false; break; }
+            if (lane == 0) { t.member[n_ent] = mm; t.count[n_ent] = 0u; }
+            __builtin_amdgcn_wave_barrier();
+            n_ent++;
+        }
+        if (!fits) { tabled_end = p0; break; }
+        for (unsigned long long rem = __ballot(have); rem;) {
+            const uint32_t mm = (uint32_t)__shfl((int)m, (int)__ffsll((long long)rem) - 1);
+            const unsigned long long mask = __ballot(have && m == mm);
+            const uint32_t e = find(mm);
+            if (lane == 0) t.count[e] += (uint32_t)__popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            rem &= ~mask;
+        }
+    }
+    if (lane < n_ent) { t.base[lane] = t.count[lane] ? atomicAdd(&cursor[t.member[lane]], (unsigned long long)t.count[lane]) : 0ull; t.run[lane] = 0u; }
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned long long p0 = lo; p0 < hi; p0 += 64u) {
+        const bool have = p0 + lane < hi;
         arp_pair q = pairs[have ? p0 + lane : p0];
-        bool uniform;
-        const uint32_t m0 = wave_owner(desc, K, q.i, have, &uniform);
-        if (uniform) {  // the wave's records go to one member: one atomic, a coalesced run
-            const unsigned long long vm = __ballot(have);
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(&cursor[m0], (unsigned long long)__popcll(vm));
-            at = wave_first_u64(at);
-            const uint32_t base = desc[m0].first_atom;
-            q.i -= base; q.j -= base;
-            if (have) grouped[at + mbcnt(vm)] = q;
-        } else if (have) {
-            const uint32_t m = pack_owner(desc, K, q.i, &PackDesc::first_atom), base = desc[m].first_atom;
-            q.i -= base; q.j -= base;
-            grouped[atomicAdd(&cursor[m], 1ull)] = q;
+        const uint32_t m = lane_owner(desc, K, q.i, have, oc);
+        for (unsigned long long rem = __ballot(have); rem;) {
+            const uint32_t mm = (uint32_t)__shfl((int)m, (int)__ffsll((long long)rem) - 1);
+            const bool mine = have && m == mm;
+            const unsigned long long mask = __ballot(mine);
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            unsigned long long at;
+            if (p0 < tabled_end) {
+                const uint32_t e = find(mm);
+                at = t.base[e] + t.run[e];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) t.run[e] += cnt;
+                __builtin_amdgcn_wave_barrier();
+            } else {  // beyond the table: places reserved per 64 records
+                at = 0;
+                if (lane == 0) at = atomicAdd(&cursor[mm], (unsigned long long)cnt);
+                at = wave_first_u64(at);
+            }
+            if (mine) {
+                const uint32_t base = desc[mm].first_atom;
+                q.i -= base; q.j -= base;
+                grouped[at + mbcnt(mask)] = q;
+            }
+            rem &= ~mask;
         }
     }
 }
@@ -144,8 +223,8 @@ void launch_pack_fix(const PackArrays &pa, hipStream_t st) {
 }
 void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, bool ordered, hipStream_t st) {
     (void)hipMemsetAsync(pa.count, 0, sizeof(unsigned long long) * pa.K, st);
-    hipLaunchKernelGGL(k_split_count, dim3(1024), dim3(256), 0, st, result, pairs, pa.K, (const PackDesc *)pa.desc, pa.count);
+    hipLaunchKernelGGL(k_split_count, dim3(kSplitBlocks), dim3(kSplitThreads), 0, st, result, pairs, pa.K, (const PackDesc *)pa.desc, pa.count);
     hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, st, pa.K, (const unsigned long long *)pa.count, pa.offset, pa.cursor);
     (void)ordered;
-    hipLaunchKernelGGL(k_split_scatter, dim3(1024), dim3(256), 0, st, result, pairs, grouped, pa.K, (const PackDesc *)pa.desc, pa.cursor);
+    hipLaunchKernelGGL(k_split_scatter, dim3(kSplitBlocks), dim3(kSplitThreads), 0, st, result, pairs, grouped, pa.K, (const PackDesc *)pa.desc, pa.cursor);
 }

@@ -611,8 +611,8 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
 
 // ---- pair lists that share one pinned block (the batch path) --------------------------------------------------------------------
 // A pack's pair list crosses PCIe once, into ONE pinned block, and every member's arp_pairs is a view into it: no per-member malloc, no
-// second copy (70 KB of records per 5k-atom structure: the copies out of the landing block were most of the batch path's time with
-// full candidate lists).  The block is reference-counted through a registry keyed by the members' data pointers -- arp_pairs_free
+// second copy (~70 k records = 1.1 MB per 5k-atom structure with full candidate lists: crossing PCIe once is the floor of that path,
+// ~20 us per structure).  The block is reference-counted through a registry keyed by the members' data pointers -- arp_pairs_free
 // finds it there -- and an idle block goes back to a pool instead of to the driver: pinning memory costs far more than the copy it saves.
 namespace {
 struct SharedBlock { char *pinned = nullptr; size_t cap = 0; long refs = 0; };
@@ -716,6 +716,17 @@ void run_helpers(int helpers, size_t n, F &&fn) {  // fn(item) over [0, n) on up
     for (auto &t : th) t.join();
 }
 
+const bool g_batch_timing = getenv("ARP_TIMING") != nullptr;
+struct BatchLap {  // ARP_TIMING=1: where a pack's host time goes (stderr)
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!g_batch_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "    batch %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 struct BatchSlot {
     arp_context *ctx = nullptr;
     PackPlan plan;
@@ -789,7 +800,9 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
     // output guess: contacts-only lists hold ~1 record per atom, full candidate lists ~15-30; a pack that needs more is re-run (finalize)
     const bool only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
     const uint64_t guess = std::max<uint64_t>((only ? 4u : 32u) * pk.n, 1u << 16);
+    BatchLap lap;
     if ((s = ensure_pack_buffers(ctx, lay.total, std::max(guess, ctx->out_cap), K)) != ARP_OK) return s;
+    lap("launch: buffers");
     char *pin = ctx->st.pinned, *dev = ctx->st.dev;
     // member offsets (serial: three running sums), then the copies -- the only per-atom host work of the batch path
     sl.first_atom.assign(K + 1, 0);
@@ -819,6 +832,7 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
         memcpy(seg(PackLayout::RES_CB) + 4ull * d.first_res, a.res_cb, a.n_res * 4); memcpy(seg(PackLayout::RES_SG) + 4ull * d.first_res, a.res_sg, a.n_res * 4);
         if (nh) memcpy(seg(PackLayout::RES_H_IDX) + 4ull * d.first_h, a.res_h_idx, nh * 4);
     });
+    lap("launch: assemble (host)");
     HIP_TRY(hipMemcpyAsync(dev, pin, lay.upload, hipMemcpyHostToDevice, ctx->stream));
     auto at = [&](int k) { return dev + lay.off[k]; };
     PackArrays &pa = sl.pa;
@@ -838,6 +852,7 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
     sl.ordered = false;  // (ordered calls are never packed, see the plan)
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     if ((s = enqueue_pack_kernels(sl, params)) != ARP_OK) return s;
+    lap("launch: enqueue");
     sl.in_flight = true;
     return ARP_OK;
 }
@@ -853,8 +868,10 @@ arp_status finalize_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
     unsigned long long total = 0;
+    BatchLap lap;
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        lap("finalize: wait for kernels");
         const uint32_t pack_status = *reinterpret_cast<const uint32_t *>(ctx->h_offsets + K + 1);
         s = flags_to_status(ctx->h_result[1]);
         if (s == kRetryDefer && attempt < 4) {  // deferred-probe list too small: grow it, run the pack's kernels again
@@ -877,6 +894,7 @@ arp_status finalize_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp
     SharedBlock *blk = nullptr;
     if (total) {
         if (!(blk = shared_acquire(total * sizeof(arp_pair)))) { set_error("out of pinned host memory for the batch's pair lists"); return ARP_ERR_OOM; }
+        lap("finalize: pinned block");
         hipError_t e = hipMemcpyAsync(blk->pinned, ctx->grp_buf, total * sizeof(arp_pair), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -886,6 +904,7 @@ arp_status finalize_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp
             return ARP_ERR_HIP;
         }
     }
+    lap("finalize: D2H of the lists");
     const unsigned long long *off = ctx->h_offsets;
     std::lock_guard<std::mutex> lk(g_shared_mu);
     for (uint64_t m = 0; m < K; m++) {  // every member's list is a view into the pack's block (arp_pairs_free drops the reference)

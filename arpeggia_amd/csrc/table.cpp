@@ -333,15 +333,27 @@ TableCache *table_cache_of(arp_structure *s) {
     if (s->table_cache) return (TableCache *)s->table_cache;
     TableCache *c = new TableCache();
     const size_t n = s->n, nr = s->residues.size();
+    const bool timing = getenv("ARP_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "    table cache %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     plane_atom_bits(*s, &c->plane_bits, &c->has_ring, &c->has_sc);
+    lap("plane bits");
     c->res_atom_ptr.assign(nr + 1, 0);
     for (size_t r = 0; r < nr; r++) c->res_atom_ptr[r + 1] = c->res_atom_ptr[r] + (uint32_t)s->residues[r].atoms.size();
     c->res_atom_idx.resize(c->res_atom_ptr[nr]);
     parallel_for(nr, 4096, [&](size_t r0, size_t r1, size_t) {
         for (size_t r = r0; r < r1; r++) std::copy(s->residues[r].atoms.begin(), s->residues[r].atoms.end(), c->res_atom_idx.begin() + c->res_atom_ptr[r]);
     });
+    lap("residue CSR");
     build_planes(*s, true, c->has_ring, nullptr, &c->rings, &c->ring_idx, &c->ring_first);
+    lap("ring entities");
     build_planes(*s, false, c->has_sc, nullptr, &c->scp, &c->sc_idx, &c->sc_first);
+    lap("sc-plane entities");
     c->direct = !c->sc_first.empty() || s->residues.empty();
     // model tables: ordinal -> serial, and the rank of the serial (sort key `model`, mod.rs:122)
     {
@@ -392,6 +404,7 @@ TableCache *table_cache_of(arp_structure *s) {
         }
         c->ring_keys[k] = EntKey{r.resi, be32s(r.altloc), 0, be32s(r.icode)};  // complex.rs:334-342: atomi 0
     }
+    lap("keys + sc sources");
     // the entity book: names and numbers of every atom and ring, gathered once
     c->book = std::make_shared<EntityBook>();
     c->book->ent.resize(n + c->rings.size());
@@ -417,6 +430,7 @@ TableCache *table_cache_of(arp_structure *s) {
         e.resi = r.resi; e.atomi = 0; e.atom = -1; e.model = (uint32_t)r.model_serial;
         c->book->lens[n + k] = lens_of(e);
     }
+    lap("entity book");
     s->table_cache = c; s->table_cache_free = free_table_cache;
     return c;
 }

@@ -25,7 +25,8 @@ atoms = sum(s.n_atoms for s in structs)
 canon = lambda a: a[np.lexsort((a["j"], a["i"]))]
 arr = (C.POINTER(_lib.arp_atoms) * n_structs)(*[C.pointer(v) for v in views])
 handles = (C.c_void_p * 1)(ctx._h)
-for only in ((True,) if trace_only else (True, False)):
+modes = {"all": (False,), "contacts": (True,)}.get(__import__("os").environ.get("ARP_BATCH_MODE", ""), (True,) if trace_only else (True, False))
+for only in modes:
     prm = aa.default_params(contacts_only=only)
     n_single = min(n_structs, 8 if trace_only else 256)
     ctx.atomic_contacts(views[0], prm)

@@ -43,9 +43,12 @@ def c_call(threads, host):
 
 
 ref = None
-for host in ((False,) if os.environ.get("ARP_DEVICE_ONLY") else (False, True)):  # ARP_DEVICE_ONLY=1: skip the round-1 host assembly (profiling runs)
+has_host_assembly = "hosttable" in os.environ.get("ARPEGGIA_AMD_LIB", "")  # only the test-only library contains the round-1 host assembly
+first = c_call(16, False)  # first call on this structure: uploads the resident copy, builds the entity book, fits the planes
+print(f"S1 {s.n_atoms} atoms, device table, 16 host thread(s), FIRST call on the structure: get_contacts {first[0] * 1e3:7.1f} ms", file=sys.stderr)
+for host in ((False, True) if has_host_assembly and not os.environ.get("ARP_DEVICE_ONLY") else (False,)):
     for threads in (1, 16):
-        c_call(threads, host)  # first call of a structure uploads it / builds its entity tables
+        c_call(threads, host)
         best = min((c_call(threads, host) for _ in range(3)), key=lambda r: r[0] + r[1])
         print(f"S1 {s.n_atoms} atoms, {'host assembly (round 1)' if host else 'device table'}, {threads:2d} host thread(s): "
               f"get_contacts {best[0] * 1e3:7.1f} ms + Arrow export {best[1] * 1e3:6.1f} ms, {best[2]} rows", file=sys.stderr)
