@@ -264,8 +264,10 @@ struct EntityRec {
 };
 static_assert(sizeof(EntityRec) == 48, "EntityRec layout");
 struct EntityBook {              // every entity a table of this structure can mention; immutable, shared by the tables (which may outlive the structure)
-    std::vector<EntityRec> ent;  // atoms, then rings
-    std::vector<uint32_t> lens;  // string lengths of an entity, 4 bits each: chain, resn, atomn, insertion, altloc
+    // (plain arrays, not vectors: 52 bytes per entity that every worker writes once -- a vector would zero them first, on one thread)
+    std::unique_ptr<EntityRec[]> ent;  // atoms, then rings
+    std::unique_ptr<uint32_t[]> lens;  // string lengths of an entity, 4 bits each: chain, resn, atomn, insertion, altloc
+    size_t n = 0;
 };
 
 struct arp_table {
@@ -317,11 +319,13 @@ struct TableCache {
     std::vector<EntKey> ring_keys;
     std::vector<uint32_t> ring_model_rank;
     std::shared_ptr<EntityBook> book;
+    std::thread book_job;                     // fills `book` while the first call's device work runs; joined before a table gets the book
+    void wait_for_book() { if (book_job.joinable()) book_job.join(); }
     std::mutex mu;                            // held for the whole of a device-table call on this structure
     std::string rings_groups; bool have_rings_dev = false;   // the ring entities as the device wants them, for this chain-group spec
     std::vector<RingEnt> rings_dev;
     DevStructure dev;
-    ~TableCache() { if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); } }
+    ~TableCache() { wait_for_book(); if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); } }
 };
 void free_table_cache(void *p) { delete (TableCache *)p; }
 uint32_t be32(const char *p) { return ((uint32_t)(unsigned char)p[0] << 24) | ((uint32_t)(unsigned char)p[1] << 16) | ((uint32_t)(unsigned char)p[2] << 8) | (uint32_t)(unsigned char)p[3]; }
@@ -352,9 +356,11 @@ TableCache *table_cache_of(arp_structure *s) {
     lap("residue CSR");
     build_planes(*s, true, c->has_ring, nullptr, &c->rings, &c->ring_idx, &c->ring_first);
     lap("ring entities");
-    build_planes(*s, false, c->has_sc, nullptr, &c->scp, &c->sc_idx, &c->sc_first);
+    // A file with a single model holds one residue per (chain, resi, icode): an entity's side-chain plane can only be its own residue's,
+    // and the keyed entries (one per residue and conformer) are needed for multi-model files only.
+    c->direct = s->chains.empty() || s->chains.back().model_idx == 0;
+    if (!c->direct) build_planes(*s, false, c->has_sc, nullptr, &c->scp, &c->sc_idx, &c->sc_first);
     lap("sc-plane entities");
-    c->direct = !c->sc_first.empty() || s->residues.empty();
     // model tables: ordinal -> serial, and the rank of the serial (sort key `model`, mod.rs:122)
     {
         const uint32_t nm = s->chains.empty() ? 1u : s->chains.back().model_idx + 1u;
@@ -384,7 +390,7 @@ TableCache *table_cache_of(arp_structure *s) {
             const uint32_t a0 = ri.atoms[0];
             src_of_alt.assign(ri.altlocs.size(), ARP_NONE);
             for (size_t k = 0; k < ri.altlocs.size(); k++) {
-                if (c->direct) { if (c->sc_first[r] >= 0) src_of_alt[k] = (uint32_t)r; continue; }
+                if (c->direct) { if (c->has_sc[r]) src_of_alt[k] = (uint32_t)r; continue; }
                 auto f = c->sc_idx.find(plane_key(s->model_serial[a0], s->chain.at(a0), s->resi[a0], s->icode.at(a0), ri.altlocs[k].c_str(), s->res_resn.at(a0)));
                 if (f != c->sc_idx.end()) src_of_alt[k] = c->scp[f->second].res;
             }
@@ -397,7 +403,7 @@ TableCache *table_cache_of(arp_structure *s) {
     c->ring_keys.resize(c->rings.size());
     for (size_t k = 0; k < c->rings.size(); k++) {
         const PlaneEntry &r = c->rings[k];
-        if (c->direct) { if (c->sc_first[r.res] >= 0) c->ring_sc_src[k] = r.res; }  // same residue, same conformer altloc
+        if (c->direct) { if (c->has_sc[r.res]) c->ring_sc_src[k] = r.res; }  // same residue, same conformer altloc
         else {
             auto f = c->sc_idx.find(plane_key(r.model_serial, r.chain.c_str(), r.resi, r.icode.c_str(), r.altloc.c_str(), r.resn.c_str()));
             if (f != c->sc_idx.end()) c->ring_sc_src[k] = c->scp[f->second].res;
@@ -405,32 +411,44 @@ TableCache *table_cache_of(arp_structure *s) {
         c->ring_keys[k] = EntKey{r.resi, be32s(r.altloc), 0, be32s(r.icode)};  // complex.rs:334-342: atomi 0
     }
     lap("keys + sc sources");
-    // the entity book: names and numbers of every atom and ring, gathered once
+    // The entity book: names and numbers of every atom and ring, gathered once.  Only the tables' string columns read it, so it is filled
+    // by a job of its own while the first call's uploads and kernels run; get_contacts_device waits for it before it hands out a table.
     c->book = std::make_shared<EntityBook>();
-    c->book->ent.resize(n + c->rings.size());
-    c->book->lens.resize(n + c->rings.size());
-    auto lens_of = [](const EntityRec &e) {
-        auto len = [](const char *p, int w) { int k = 0; while (k < w && p[k]) k++; return (uint32_t)k; };
-        return len(e.chain, 8) | (len(e.resn, 8) << 4) | (len(e.atomn, 8) << 8) | (len(e.insertion, 4) << 12) | (len(e.altloc, 4) << 16);
-    };
-    parallel_for(n, 1u << 14, [&](size_t a0, size_t a1, size_t) {
-        for (size_t a = a0; a < a1; a++) {  // structs.rs:109-119
-            EntityRec &e = c->book->ent[a];
-            memcpy(e.chain, s->chain.at(a), 8); memcpy(e.resn, s->res_resn.at(a), 8); memcpy(e.atomn, s->name.at(a), 8);
-            memcpy(e.insertion, s->icode.at(a), 4); memcpy(e.altloc, s->altloc.at(a), 4);
-            e.resi = s->resi[a]; e.atomi = s->serial[a]; e.atom = (int32_t)a; e.model = (uint32_t)s->model_serial[a];
-            c->book->lens[a] = lens_of(e);
-        }
-    });
-    for (size_t k = 0; k < c->rings.size(); k++) {  // complex.rs:334-342
-        const PlaneEntry &r = c->rings[k];
-        EntityRec &e = c->book->ent[n + k];
-        auto put = [](char *dst, size_t cap, const std::string &v) { memset(dst, 0, cap); memcpy(dst, v.data(), std::min(cap - 1, v.size())); };
-        put(e.chain, 8, r.chain); put(e.resn, 8, r.resn); put(e.atomn, 8, "Ring"); put(e.insertion, 4, r.icode); put(e.altloc, 4, r.altloc);
-        e.resi = r.resi; e.atomi = 0; e.atom = -1; e.model = (uint32_t)r.model_serial;
-        c->book->lens[n + k] = lens_of(e);
+    {
+        EntityBook *bk = c->book.get();
+        bk->n = n + c->rings.size();
+        bk->ent.reset(new EntityRec[bk->n]);
+        bk->lens.reset(new uint32_t[bk->n]);
+        const int workers = host_threads();
+        const arp_structure *sp = s;
+        const TableCache *cp = c;
+        c->book_job = std::thread([bk, sp, cp, workers]() {
+            HostThreadsScope scope(workers);
+            const size_t n_atoms = sp->n;
+            auto lens_of = [](const EntityRec &e) {
+                auto len = [](const char *p, int w) { int k = 0; while (k < w && p[k]) k++; return (uint32_t)k; };
+                return len(e.chain, 8) | (len(e.resn, 8) << 4) | (len(e.atomn, 8) << 8) | (len(e.insertion, 4) << 12) | (len(e.altloc, 4) << 16);
+            };
+            parallel_for(n_atoms, 1u << 14, [&](size_t a0, size_t a1, size_t) {
+                for (size_t a = a0; a < a1; a++) {  // structs.rs:109-119
+                    EntityRec &e = bk->ent[a];
+                    memcpy(e.chain, sp->chain.at(a), 8); memcpy(e.resn, sp->res_resn.at(a), 8); memcpy(e.atomn, sp->name.at(a), 8);
+                    memcpy(e.insertion, sp->icode.at(a), 4); memcpy(e.altloc, sp->altloc.at(a), 4);
+                    e.resi = sp->resi[a]; e.atomi = sp->serial[a]; e.atom = (int32_t)a; e.model = (uint32_t)sp->model_serial[a];
+                    bk->lens[a] = lens_of(e);
+                }
+            });
+            for (size_t k = 0; k < cp->rings.size(); k++) {  // complex.rs:334-342
+                const PlaneEntry &r = cp->rings[k];
+                EntityRec &e = bk->ent[n_atoms + k];
+                auto put = [](char *dst, size_t cap, const std::string &v) { memset(dst, 0, cap); memcpy(dst, v.data(), std::min(cap - 1, v.size())); };
+                put(e.chain, 8, r.chain); put(e.resn, 8, r.resn); put(e.atomn, 8, "Ring"); put(e.insertion, 4, r.icode); put(e.altloc, 4, r.altloc);
+                e.resi = r.resi; e.atomi = 0; e.atom = -1; e.model = (uint32_t)r.model_serial;
+                bk->lens[n_atoms + k] = lens_of(e);
+            }
+        });
     }
-    lap("entity book");
+    lap("entity book (job started)");
     s->table_cache = c; s->table_cache_free = free_table_cache;
     return c;
 }
@@ -492,12 +510,22 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
         uint64_t total = 0;
         for (const Seg &g : seg) total += (g.bytes + 255u) & ~255ull;
         total = std::max<uint64_t>(total, 256);
+        const bool timing = getenv("ARP_TIMING") != nullptr;
+        auto t_prev = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "    resident %-25s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+            t_prev = now;
+        };
         TBL_HIP(hipMalloc((void **)&d.block, total));
+        lap("device block");
         d.device = device;
         // one pinned staging block, filled by the host workers, one copy across PCIe (pageable arrays cross at ~3 GB/s)
         char *dev_scr = nullptr, *pin = nullptr;
         arp_status stt = context_scratch(ctx, 1, 0, total, &dev_scr, &pin);
         if (stt != ARP_OK) return stt;
+        lap("pinned staging block");
         uint64_t off = 0;
         std::vector<uint64_t> offs;
         for (const Seg &g : seg) { offs.push_back(off); *g.dst = d.block + off; off += (g.bytes + 255u) & ~255ull; }
@@ -509,13 +537,16 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
                 if (hi > lo) memcpy(pin + offs[k / 8] + lo, (const char *)g.src + lo, hi - lo);
             }
         });
+        lap("gather into it");
         TBL_HIP(hipMemcpyAsync(d.block, pin, total, hipMemcpyHostToDevice, st));
         TBL_HIP(hipStreamSynchronize(st));  // (the pinned block is scratch: reused by the table pass below)
+        lap("H2D");
         d.n = n; d.n_res = nr; d.n_h = nh;
         d.n_chains = (uint32_t)s->chain_ids.size(); d.n_models = (uint32_t)nm;
         d.any_icode = false;
         for (uint64_t a = 1; a < n && !d.any_icode; a++) d.any_icode = c->atom_keys[a].icode != c->atom_keys[0].icode;  // (rings carry their residue's: the same values)
         d.attr_groups = groups;
+        lap("insertion-code scan");
     } else if (d.attr_groups != groups) {
         TBL_HIP(hipMemcpyAsync(d.attr, s->attr.data(), n * 4, hipMemcpyHostToDevice, st));
         TBL_HIP(hipStreamSynchronize(st));
@@ -587,6 +618,7 @@ arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *g
     arp_table *t = new arp_table();
     t->n = rows.n;
     t->rows_owner = std::move(rows.owner); t->rows = rows.rows; t->sc = rows.sc;
+    c->wait_for_book();
     t->book = c->book;
     lap("table object");
     *out = t;

@@ -45,7 +45,12 @@ def c_call(threads, host):
 ref = None
 has_host_assembly = "hosttable" in os.environ.get("ARPEGGIA_AMD_LIB", "")  # only the test-only library contains the round-1 host assembly
 first = c_call(16, False)  # first call on this structure: uploads the resident copy, builds the entity book, fits the planes
-print(f"S1 {s.n_atoms} atoms, device table, 16 host thread(s), FIRST call on the structure: get_contacts {first[0] * 1e3:7.1f} ms", file=sys.stderr)
+print(f"S1 {s.n_atoms} atoms, device table, 16 host thread(s), FIRST call of the process: get_contacts {first[0] * 1e3:7.1f} ms", file=sys.stderr)
+c_call(16, False)
+s_first, s = s, aa.Structure.from_records(rec, hierarchy=True)  # a second structure of the same size: its first call, in a process that has run one
+print("-- second structure --", file=sys.stderr)
+first = c_call(16, False)
+print(f"S1 {s.n_atoms} atoms, device table, 16 host thread(s), FIRST call on a second structure: get_contacts {first[0] * 1e3:7.1f} ms", file=sys.stderr)
 for host in ((False, True) if has_host_assembly and not os.environ.get("ARP_DEVICE_ONLY") else (False,)):
     for threads in (1, 16):
         c_call(threads, host)
