@@ -41,6 +41,7 @@ struct DevStructure {
     // derived once per structure by the first device_table call (they depend on the structure alone): the fitted planes and the entity ranks
     char *derived = nullptr;             // one allocation
     void *ring_pl = nullptr, *sc_pl = nullptr; uint8_t *pl_valid = nullptr; uint32_t *ent_rank = nullptr; uint64_t derived_n_ent = 0;
+    uint32_t max_ent_rank = 0;           // largest rank of an entity inside its chain (the width of a rank in the rows' sort key)
     uint32_t n_chains = 0, n_models = 0;  // distinct chain ids / models of the structure (widths of the sort keys)
     bool any_icode = false;              // some atom carries an insertion code (otherwise that sort pass is skipped)
     std::string attr_groups;             // the chain groups the resident attr words were built for

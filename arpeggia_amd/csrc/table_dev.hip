@@ -233,31 +233,55 @@ __global__ __launch_bounds__(256) void k_expand_rows(const arp_pair *pairs, uint
 
 // ---- entity ranks and the 10-key sort (mod.rs:120-134) ----------------------------------------------------------------
 // model, from_chain, to_chain, from_resi, from_altloc, from_atomi, to_resi, to_altloc, to_atomi, interaction; ties (the reference's
-// sort is unstable there) by from_insertion, to_insertion, distance.  (resi, altloc, atomi) of an entity collapse into ONE dense rank,
-// computed by sorting the entities once; the rows then sort by five stable radix passes, least significant first.
+// sort is unstable there) by from_insertion, to_insertion, distance.  (resi, altloc, atomi) of an entity collapse into ONE dense rank
+// INSIDE ITS CHAIN, computed by sorting the entities once per structure: rows are only ever compared on these three keys when their
+// chains are equal, and a rank inside the chain needs bits(largest chain) instead of bits(all entities) -- which is what lets all ten keys
+// of a row share one 64-bit radix key (a million entities in 1500 chains: 48 bits instead of 68).
 __device__ inline uint32_t bias(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
-__global__ __launch_bounds__(256) void k_ent_key(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, int pass, const uint32_t *ids,
-                                                 unsigned long long *key) {
+__device__ inline uint32_t ent_chain(uint32_t e, uint32_t n_atoms, const uint16_t *chain_rank, const RingEnt *rings) {
+    return e < n_atoms ? (uint32_t)chain_rank[e] : rings[e - n_atoms].chain_rank;
+}
+__global__ __launch_bounds__(256) void k_ent_key(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint16_t *chain_rank,
+                                                 const RingEnt *rings, int pass, const uint32_t *ids, unsigned long long *key) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_ent) return;
     const uint32_t e = ids ? ids[p] : p;
+    if (pass == 2) { key[p] = ent_chain(e, n_atoms, chain_rank, rings); return; }
     const EntKey k = e < n_atoms ? atom_keys[e] : ring_keys[e - n_atoms];
     key[p] = pass == 0 ? (unsigned long long)bias(k.atomi) : (((unsigned long long)bias(k.resi) << 32) | k.altloc);
 }
-__global__ __launch_bounds__(256) void k_ent_flags(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint32_t *ids, uint32_t *flag) {
+// entities sorted by (chain, resi, altloc, atomi): flag = the key differs from the predecessor's
+__global__ __launch_bounds__(256) void k_ent_flags(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint16_t *chain_rank,
+                                                   const RingEnt *rings, const uint32_t *ids, uint32_t *flag) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_ent) return;
     auto key_of = [&](uint32_t e) { return e < n_atoms ? atom_keys[e] : ring_keys[e - n_atoms]; };
     uint32_t f = 0;
     if (p > 0) {
         const EntKey a = key_of(ids[p - 1]), b = key_of(ids[p]);
-        f = (a.resi != b.resi || a.altloc != b.altloc || a.atomi != b.atomi) ? 1u : 0u;
+        f = (a.resi != b.resi || a.altloc != b.altloc || a.atomi != b.atomi || ent_chain(ids[p - 1], n_atoms, chain_rank, rings) != ent_chain(ids[p], n_atoms, chain_rank, rings)) ? 1u : 0u;
     }
     flag[p] = f;
 }
-__global__ __launch_bounds__(256) void k_ent_rank(uint32_t n_ent, const uint32_t *ids, const uint32_t *scan, uint32_t *rank) {
+// scan = dense rank over all entities; base[chain] = the rank its first entity got
+__global__ __launch_bounds__(256) void k_ent_base(uint32_t n_ent, uint32_t n_atoms, const uint16_t *chain_rank, const RingEnt *rings, const uint32_t *ids, const uint32_t *scan,
+                                                  uint32_t *base) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n_ent) rank[ids[p]] = scan[p];
+    if (p >= n_ent) return;
+    const uint32_t c = ent_chain(ids[p], n_atoms, chain_rank, rings);
+    if (p == 0 || ent_chain(ids[p - 1], n_atoms, chain_rank, rings) != c) base[c] = scan[p];
+}
+__global__ __launch_bounds__(256) void k_ent_rank(uint32_t n_ent, uint32_t n_atoms, const uint16_t *chain_rank, const RingEnt *rings, const uint32_t *ids, const uint32_t *scan,
+                                                  const uint32_t *base, uint32_t *rank, uint32_t *max_rank) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = 0;
+    if (p < n_ent) {
+        const uint32_t e = ids[p];
+        r = scan[p] - base[ent_chain(e, n_atoms, chain_rank, rings)];
+        rank[e] = r;
+    }
+    for (int off = 32; off; off >>= 1) r = max(r, (uint32_t)__shfl_xor((int)r, off));
+    if ((threadIdx.x & 63u) == 0u && r) atomicMax(max_rank, r);
 }
 
 __global__ __launch_bounds__(256) void k_iota(uint32_t n_items, uint32_t *v) {
@@ -291,6 +315,50 @@ __global__ __launch_bounds__(256) void k_row_key(uint32_t n_rows, const uint4 *r
         }
     }
     key[p] = k;
+}
+
+// The ten keys tie only between rows that mention the same two entities with the same interaction: twice the same ring-ring pair of a
+// residue with two rings, or atoms that share (resi, altloc, atomi).  Instead of sorting EVERY row by insertion codes and distance first
+// (five more radix passes over the table), the sorted rows are inspected once: a row whose neighbour carries the same keys finds its run
+// and takes the place its (from_insertion, to_insertion, distance, position) earns inside it.  Runs longer than kTieRun raise `overflow`
+// and the host sorts again the long way.
+constexpr uint32_t kTieRun = 64;
+__global__ __launch_bounds__(256) void k_tie_fix(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, const unsigned long long *sorted_key, uint32_t n_atoms,
+                                                 const EntKey *atom_keys, const EntKey *ring_keys, const uint32_t *ent_rank, const uint16_t *chain_rank, const uint16_t *model,
+                                                 const uint32_t *model_rank, const RingEnt *rings, uint32_t *perm_out, uint32_t *overflow) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_rows) return;
+    auto same = [&](uint32_t a, uint32_t b) {  // rows at sorted positions a, b carry the same ten keys
+        if (sorted_key) return sorted_key[a] == sorted_key[b];
+        const uint4 ra = rows[perm[a]], rb = rows[perm[b]];
+        if (ra.w != rb.w || ent_rank[ra.x] != ent_rank[rb.x] || ent_rank[ra.y] != ent_rank[rb.y]) return false;
+        if (ent_chain(ra.x, n_atoms, chain_rank, rings) != ent_chain(rb.x, n_atoms, chain_rank, rings) ||
+            ent_chain(ra.y, n_atoms, chain_rank, rings) != ent_chain(rb.y, n_atoms, chain_rank, rings)) return false;
+        const uint32_t ma = ra.x < n_atoms ? model_rank[model[ra.x]] : rings[ra.x - n_atoms].model_rank, mb = rb.x < n_atoms ? model_rank[model[rb.x]] : rings[rb.x - n_atoms].model_rank;
+        return ma == mb;
+    };
+    const bool tie_prev = p > 0 && same(p - 1, p), tie_next = p + 1 < n_rows && same(p, p + 1);
+    if (!tie_prev && !tie_next) { perm_out[p] = perm[p]; return; }
+    uint32_t lo = p, hi = p + 1;  // the run [lo, hi)
+    while (lo > 0 && p - lo < kTieRun && same(lo - 1, lo)) lo--;
+    while (hi < n_rows && hi - p < kTieRun && same(hi - 1, hi)) hi++;
+    if (p - lo >= kTieRun || hi - p >= kTieRun) { *overflow = 1u; perm_out[p] = perm[p]; return; }
+    auto ins_of = [&](uint32_t e) { return e < n_atoms ? atom_keys[e].icode : ring_keys[e - n_atoms].icode; };
+    auto tie_key = [&](uint32_t q, unsigned long long *ins, uint32_t *dist) {
+        const uint4 r = rows[perm[q]];
+        *ins = ((unsigned long long)ins_of(r.x) << 32) | ins_of(r.y); *dist = r.z;  // (non-negative f32: bit order == value order)
+    };
+    unsigned long long my_ins; uint32_t my_dist;
+    tie_key(p, &my_ins, &my_dist);
+    uint32_t before = 0;
+    for (uint32_t q = lo; q < hi; q++) {
+        if (q == p) continue;
+        unsigned long long ins; uint32_t dist;
+        tie_key(q, &ins, &dist);
+        const bool less = ins != my_ins ? ins < my_ins : (dist != my_dist ? dist < my_dist : q < p);
+        before += less ? 1u : 0u;
+    }
+    perm_out[lo + before] = perm[p];
 }
 
 // final order + collect_sc_stats (complex.rs:137-174): res1 = ligand residue, res2 = receptor residue
@@ -390,7 +458,7 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
     RingEnt *d_rings = b.take<RingEnt>(n_rings);
     EntKey *d_ring_keys = b.take<EntKey>(n_rings);
     RingPoint *ring_pts = b.take<RingPoint>(n_rings);
-    uint32_t *counters = b.take<uint32_t>(64);  // [0] rows
+    uint32_t *counters = b.take<uint32_t>(64);  // [0] rows, [1] tie runs too long for k_tie_fix, [2] largest entity rank
     uint32_t *bits = b.take<uint32_t>(n_pairs + 1), *first = b.take<uint32_t>(n_pairs + 1);
     char *cub_tmp = b.take<char>(std::max(cub_scan, cub_sort_ent));
     unsigned long long *ek0 = b.take<unsigned long long>(n_ent), *ek1 = b.take<unsigned long long>(n_ent);
@@ -414,23 +482,37 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         size_t tmp = cub_scan;
         TRY_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, (const uint32_t *)bits, first, (int)n_pairs + 1, st));
     }
-    // entity ranks: sort the entities by (resi, altloc, atomi), least significant key first; rank = number of key changes before
+    // entity ranks: sort the entities by (chain, resi, altloc, atomi), least significant key first; rank = number of key changes since the
+    // chain's first entity
     if (derive) {
+        const uint16_t *chain = (const uint16_t *)ds.chain_rank;
         hipLaunchKernelGGL(k_iota, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, eid0);
-        hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, 0,
-                           (const uint32_t *)nullptr, ek0);
+        hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, chain,
+                           (const RingEnt *)d_rings, 0, (const uint32_t *)nullptr, ek0);
         size_t tmp = cub_sort_ent;
         TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tmp, (const unsigned long long *)ek0, ek1, (const uint32_t *)eid0, eid1, (int)n_ent, 0, 32, st));
-        hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, 1,
-                           (const uint32_t *)eid1, ek0);
+        hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, chain,
+                           (const RingEnt *)d_rings, 1, (const uint32_t *)eid1, ek0);
         tmp = cub_sort_ent;
         TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tmp, (const unsigned long long *)ek0, ek1, (const uint32_t *)eid1, eid0, (int)n_ent, 0, 64, st));
-        hipLaunchKernelGGL(k_ent_flags, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys,
-                           (const uint32_t *)eid0, eflag);
+        hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, chain,
+                           (const RingEnt *)d_rings, 2, (const uint32_t *)eid0, ek0);
+        tmp = cub_sort_ent;
+        TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tmp, (const unsigned long long *)ek0, ek1, (const uint32_t *)eid0, eid1, (int)n_ent, 0, 16, st));
+        hipLaunchKernelGGL(k_ent_flags, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, chain,
+                           (const RingEnt *)d_rings, (const uint32_t *)eid1, eflag);
         tmp = cub_scan;
-        TRY_HIP(hipcub::DeviceScan::InclusiveSum(cub_tmp, tmp, (const uint32_t *)eflag, eid1, (int)n_ent, st));
-        hipLaunchKernelGGL(k_ent_rank, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const uint32_t *)eid0, (const uint32_t *)eid1, ent_rank);
+        TRY_HIP(hipcub::DeviceScan::InclusiveSum(cub_tmp, tmp, (const uint32_t *)eflag, eid0, (int)n_ent, st));
+        uint32_t *chain_base = reinterpret_cast<uint32_t *>(ek0);  // (the sort keys are done with: 65536 words of them hold the per-chain bases)
+        hipLaunchKernelGGL(k_ent_base, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (uint32_t)n, chain, (const RingEnt *)d_rings, (const uint32_t *)eid1, (const uint32_t *)eid0,
+                           chain_base);
+        hipLaunchKernelGGL(k_ent_rank, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (uint32_t)n, chain, (const RingEnt *)d_rings, (const uint32_t *)eid1, (const uint32_t *)eid0,
+                           (const uint32_t *)chain_base, ent_rank, counters + 2);
         TRY_HIP(hipGetLastError());
+        uint32_t max_rank = 0;  // (once per structure: the width of a rank in the rows' sort key)
+        TRY_HIP(hipMemcpyAsync(&max_rank, counters + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipStreamSynchronize(st));
+        ds.max_ent_rank = max_rank;
     }
     lap("planes+bits+ranks");
     // how many atom rows?  (one small read-back: the row buffers are sized by it)
@@ -470,7 +552,6 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
     TRY_HIP(hipStreamSynchronize(st));
     if (n_rows > rows_cap) { set_error("internal error: more ring rows than reserved (%u > %llu)", n_rows, (unsigned long long)rows_cap); return ARP_ERR_HIP; }
     lap("rows");
-    // the sort: five stable passes, least significant key first
     SortTables tb{};
     {
         int o[ARP_N_INTERACTIONS];
@@ -478,16 +559,19 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         std::sort(o, o + ARP_N_INTERACTIONS, [](int a, int c) { return strcmp(arp_interaction_name(a), arp_interaction_name(c)) < 0; });
         for (int k = 0; k < ARP_N_INTERACTIONS; k++) tb.name_rank[o[k]] = (uint8_t)k;
     }
-    if (n_rows) {
+    // The sort: stable radix passes over row indices, least significant key first.  The entity ranks, interaction, chains and model go
+    // into ONE key when their actual widths fit 64 bits (else two or three passes); rows whose ten keys tie are put in order afterwards
+    // (k_tie_fix).  `long_way`: the tie-breaking keys -- insertion codes (skipped when no atom carries one), distance -- as passes of their own.
+    auto width = [](uint64_t v) { uint32_t b = 1; while (b < 32 && (1ull << b) < v) b++; return b; };  // bits that hold 0 .. v-1
+    tb.rank_bits = width((uint64_t)ds.max_ent_rank + 1); tb.chain_bits = width(std::max<uint64_t>(ds.n_chains, 1));
+    auto sort_and_finish = [&](bool long_way) -> arp_status {
         hipLaunchKernelGGL(k_iota, grid(n_rows, 256), dim3(256), 0, st, n_rows, perm0);
-        // Least significant key first: distance; the insertion codes (skipped when no atom carries one: a constant key); then the entity
-        // ranks, interaction, chains and model -- as ONE key when their actual widths fit 64 bits, else as two or three.
-        auto bits = [](uint64_t v) { uint32_t b = 1; while (b < 32 && (1ull << b) < v) b++; return b; };  // width that holds 0 .. v-1
-        tb.rank_bits = bits(n_ent); tb.chain_bits = bits(std::max<uint64_t>(ds.n_chains, 1));
-        const uint32_t model_bits = bits(std::max<uint64_t>(ds.n_models, 1)), top = model_bits + 2 * tb.chain_bits;
+        const uint32_t model_bits = width(std::max<uint64_t>(ds.n_models, 1)), top = model_bits + 2 * tb.chain_bits;
         int plan[5], end_bit[5], n_pass = 0;
-        plan[n_pass] = 0; end_bit[n_pass++] = 32;
-        if (ds.any_icode) { plan[n_pass] = 1; end_bit[n_pass++] = 64; }
+        if (long_way) {
+            plan[n_pass] = 0; end_bit[n_pass++] = 32;
+            if (ds.any_icode) { plan[n_pass] = 1; end_bit[n_pass++] = 64; }
+        }
         if (top + 2 * tb.rank_bits + 5 <= 64) { plan[n_pass] = 6; end_bit[n_pass++] = (int)(top + 2 * tb.rank_bits + 5); }
         else {
             plan[n_pass] = 2; end_bit[n_pass++] = (int)(tb.rank_bits + 5);
@@ -504,36 +588,59 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
             TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp2, tmp, (const unsigned long long *)rk0, rk1, (const uint32_t *)pin_, pout, (int)n_rows, 0, end_bit[q], st));
             std::swap(pin_, pout);
         }
+        if (!long_way) {
+            const bool one_key = plan[n_pass - 1] == 6 && n_pass == 1;  // rk1 then holds every row's ten keys, in sorted order
+            hipLaunchKernelGGL(k_tie_fix, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, one_key ? (const unsigned long long *)rk1 : nullptr,
+                               (uint32_t)n, (const EntKey *)ds.ent_key, (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint16_t *)ds.chain_rank, (const uint16_t *)ds.model,
+                               (const uint32_t *)ds.model_rank, (const RingEnt *)d_rings, pout, counters + 1);
+            std::swap(pin_, pout);
+        }
         hipLaunchKernelGGL(k_finish_rows, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, (uint32_t)n, (const uint32_t *)ds.atom_sc_src,
                            (const RingEnt *)d_rings, (const PlaneD *)sc_pl, (const uint8_t *)valid, out_rows, out_sc);
         TRY_HIP(hipGetLastError());
+        return ARP_OK;
+    };
+    uint32_t *tie_overflow = reinterpret_cast<uint32_t *>(pin + 2 * al(rows_cap * 16));  // (pinned, behind the landing area: read back with the rows)
+    *tie_overflow = 0u;
+    if (n_rows) {
+        if ((s = sort_and_finish(false)) != ARP_OK) return s;
+        TRY_HIP(hipMemcpyAsync(tie_overflow, counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         lap("sort+finish");
     }
     // Rows and sc values come back in ONE copy each.  A large table lands in a pooled pinned block that the table object then owns (the
     // Arrow export and the column accessors read it in place); a small one goes through the context's landing buffer into plain arrays.
     out->n = n_rows;
     const size_t row_bytes = (size_t)n_rows * 16;
+    char *heap = nullptr;
     if (row_bytes >= (1u << 20)) {
         out->owner = pinned_block(2 * al(row_bytes));
         if (!out->owner) { set_error("out of pinned host memory for the table"); return ARP_ERR_OOM; }
         out->rows = reinterpret_cast<TableRow *>(out->owner.get());
         out->sc = reinterpret_cast<TableSc *>(out->owner.get() + al(row_bytes));
-        TRY_HIP(hipMemcpyAsync(out->rows, out_rows, row_bytes, hipMemcpyDeviceToHost, st));
-        TRY_HIP(hipMemcpyAsync(out->sc, out_sc, row_bytes, hipMemcpyDeviceToHost, st));
-        TRY_HIP(hipStreamSynchronize(st));
     } else {
-        char *heap = (char *)malloc(2 * al(row_bytes) + 64);
+        heap = (char *)malloc(2 * al(row_bytes) + 64);
         if (!heap) { set_error("out of host memory"); return ARP_ERR_OOM; }
         out->owner = std::shared_ptr<char>(heap, [](char *q) { free(q); });
         out->rows = reinterpret_cast<TableRow *>(heap);
         out->sc = reinterpret_cast<TableSc *>(heap + al(row_bytes));
-        if (n_rows) {
+    }
+    auto fetch = [&]() -> arp_status {
+        if (!heap) {
+            TRY_HIP(hipMemcpyAsync(out->rows, out_rows, row_bytes, hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipMemcpyAsync(out->sc, out_sc, row_bytes, hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipStreamSynchronize(st));
+        } else if (n_rows) {
             TRY_HIP(hipMemcpyAsync(pin, out_rows, row_bytes, hipMemcpyDeviceToHost, st));
             TRY_HIP(hipMemcpyAsync(pin + al((uint64_t)rows_cap * 16), out_sc, row_bytes, hipMemcpyDeviceToHost, st));
             TRY_HIP(hipStreamSynchronize(st));
-            memcpy(out->rows, pin, row_bytes);
-            memcpy(out->sc, pin + al((uint64_t)rows_cap * 16), row_bytes);
+            memcpy(heap, pin, row_bytes);
+            memcpy(heap + al(row_bytes), pin + al((uint64_t)rows_cap * 16), row_bytes);
         }
+        return ARP_OK;
+    };
+    if ((s = fetch()) != ARP_OK) return s;
+    if (*tie_overflow) {  // a run of more than kTieRun rows with the same ten keys: sort again with the tie-breaking keys as passes of their own
+        if ((s = sort_and_finish(true)) != ARP_OK || (s = fetch()) != ARP_OK) return s;
     }
     lap("unpack");
     return ARP_OK;

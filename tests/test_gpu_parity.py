@@ -732,6 +732,29 @@ def test_table_on_stress_structure_matches_oracle_table(ctx, tmp_path):
         _lines_close(_table_lines(cols), want)
 
 
+def test_table_with_long_runs_of_tied_sort_keys(ctx, tmp_path):
+    """Rows whose ten sort keys tie are ordered by (from_insertion, to_insertion, distance).  Here 26 residues at a time share their residue
+    NUMBER (insertion codes A..Z) and every atom of the file carries serial 5, so all rows between such residues with the same interaction tie:
+    runs far beyond the 64 rows the device's tie pass resolves in place, i.e. the table goes through the second, long-way sort -- and the
+    insertion codes decide the order.  A milder variant (serials kept) keeps the runs short: the in-place pass."""
+    base = synth.gen_stress(n_res=104, seed=77, n_chains=1, hydrogens=False)
+    key = np.char.add(np.char.add(base["chain"].astype("U8"), "|"), base["resi"].astype("U12"))
+    _, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    res_of = np.argsort(np.argsort(first))[inv]
+    for same_serial in (True, False):
+        rec = {k: v.copy() for k, v in base.items()}
+        rec["resi"] = (10 + res_of // 26).astype(rec["resi"].dtype)
+        rec["icode"] = np.array([bytes([65 + int(r) % 26]) for r in res_of], dtype=rec["icode"].dtype)
+        if same_serial:
+            rec["serial"][:] = 5
+        p = tmp_path / f"ties_{int(same_serial)}.pdb"
+        synth.write_pdb(rec, p)
+        s, o = aa.load_model(p), ob.Structure.load(p)
+        want = ob.rows_to_csv_lines(o.get_contacts("/", 0.1, 6.5))
+        assert len(want) > 2000
+        _lines_close(_table_lines(ctx.get_contacts(s, "/", 0.1, 6.5)), want)
+
+
 def test_disk_files_with_altlocs_insertion_codes_and_two_models_end_to_end(ctx, tmp_path):
     """a file with alternate locations, insertion codes and two MODEL records, read from DISK as PDB and as mmCIF (quoted
     values, a multi-line text field, wrapped rows, label_* numbering that differs from the author numbering), through contacts() to the table,
