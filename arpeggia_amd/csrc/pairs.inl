@@ -35,7 +35,7 @@ constexpr uint32_t kGrab = 1;              // wave-tasks drawn per atomic
 // records per global allocation (one device atomic each).  The wave whose allocation crosses the end of the block's chunk fetches the
 // next one while the block's other waves sleep: 2048 -> 4096 halves those stalls (emit 221 -> 208 us); 8192 gains 2 us more and costs
 // the fix-up 8 us (holes grow with the chunk).
-constexpr uint32_t kChunkRecords = 4096;
+constexpr uint32_t kChunkRecords = 4096, kSmallChunkRecords = 2048, kTinyChunkRecords = 256;  // records per allocation chunk (powers of two; the smaller ones: k_emit's 4-wave kernels)
 
 template <int MODE>
 struct WaveLds {                                  // per-wave LDS working set
@@ -45,7 +45,9 @@ struct WaveLds {                                  // per-wave LDS working set
 struct BlockLds {
     unsigned long long alloc_state;               // emit mode: current chunk index << 32 | records handed out of it
     unsigned long long defer_state;               // the same for the deferred-probe list (kDeferChunk entries per chunk)
+    uint32_t chunk_shift;                         // log2 of the records per chunk of alloc_state (one value per launch sequence: k_fixup is told)
 };
+constexpr uint32_t chunk_shift_of(uint32_t chunk) { uint32_t s = 0; while ((1u << s) < chunk) s++; return s; }
 constexpr uint32_t kDeferChunk = 512;          // deferred-list entries per global allocation
 constexpr unsigned long long kAllocEmpty = 0xFFFFFFFFull << 32;  // no chunk yet: | chunk size = "exhausted"
 
@@ -118,12 +120,13 @@ DEVFN unsigned long long alloc_issue(unsigned long long &state, uint32_t n, uint
     if (lane == 0) old = __hip_atomic_fetch_add(&state, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return old;  // (lane 0 holds the answer)
 }
-template <uint32_t CHUNK>
-DEVFN Slots alloc_finish(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane, unsigned long long old) {
+// (chunk = records per chunk, a power of two given by its log2: a constant in the hot kernel, read from the block's LDS in the others)
+DEVFN Slots alloc_finish_rt(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane, unsigned long long old, uint32_t shift) {
+    const uint32_t CHUNK = 1u << shift;
     for (;;) {
         old = wave_first_u64(old);
         const uint32_t used = (uint32_t)old, chunk = (uint32_t)(old >> 32);
-        if (used + n <= CHUNK) return Slots{(unsigned long long)chunk * CHUNK + used, 0ull, n};
+        if (used + n <= CHUNK) return Slots{((unsigned long long)chunk << shift) + used, 0ull, n};
         if (used <= CHUNK) {  // this allocation crosses the end: it alone refills
             const uint32_t n0 = CHUNK - used;
             unsigned long long nc = 0;
@@ -132,7 +135,7 @@ DEVFN Slots alloc_finish(unsigned long long &state, unsigned long long *g_head, 
                 __hip_atomic_store(&state, (nc << 32) | (unsigned long long)(n - n0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             nc = wave_first_u64(nc);
-            return Slots{(unsigned long long)chunk * CHUNK + used, nc * CHUNK, n0};
+            return Slots{((unsigned long long)chunk << shift) + used, nc << shift, n0};
         }
         // exhausted while another wave refills: sleep on the LDS word until the new chunk is published, then retry
         while ((uint32_t)(wave_first_u64(__hip_atomic_load(&state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) == chunk)
@@ -141,8 +144,16 @@ DEVFN Slots alloc_finish(unsigned long long &state, unsigned long long *g_head, 
     }
 }
 template <uint32_t CHUNK>
+DEVFN Slots alloc_finish(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane, unsigned long long old) {
+    static_assert((CHUNK & (CHUNK - 1u)) == 0u, "chunk sizes are powers of two");
+    return alloc_finish_rt(state, g_head, n, lane, old, chunk_shift_of(CHUNK));
+}
+template <uint32_t CHUNK>
 DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane) {
     return alloc_finish<CHUNK>(state, g_head, n, lane, alloc_issue(state, n, lane));
+}
+DEVFN Slots alloc_chunked_rt(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane, uint32_t shift) {
+    return alloc_finish_rt(state, g_head, n, lane, alloc_issue(state, n, lane), shift);
 }
 
 constexpr uint32_t kWaveAllBoth = 1u, kWaveContactsOnly = 2u;  // wave-uniform switches of process_batch, kept in a scalar register
@@ -241,7 +252,7 @@ DEVFN uint32_t process_batch(const DevAtoms &in, const LdsParams &prm, const Sor
             }
             const uint32_t n = (uint32_t)__popcll(vm);
             if (n) {  // compacted, coalesced store of the batch's records straight from registers
-                const Slots sl = alloc_chunked<kChunkRecords>(bl.alloc_state, &result[2], n, lane);
+                const Slots sl = alloc_chunked_rt(bl.alloc_state, &result[2], n, lane, bl.chunk_shift);
                 const uint32_t rank = mbcnt(vm);
                 if (sl.n0 == n && sl.pos0 + n <= tg.capacity) {
                     // the common case, decided on the scalar unit: one run inside the caller's buffer -> scalar base + 32-bit lane offset
@@ -274,7 +285,8 @@ DEVFN void emit_epilogue(BlockLds &bl, ulonglong2 *hole, const EmitTarget &tg) {
         const unsigned long long st = bl.alloc_state;
         const uint32_t chunk = (uint32_t)(st >> 32), used = (uint32_t)st;
         unsigned long long hs = 0, hl = 0;
-        if (chunk != 0xFFFFFFFFu && used < kChunkRecords) { hs = (unsigned long long)chunk * kChunkRecords + used; hl = kChunkRecords - used; }
+        const uint32_t per = 1u << bl.chunk_shift;
+        if (chunk != 0xFFFFFFFFu && used < per) { hs = ((unsigned long long)chunk << bl.chunk_shift) + used; hl = per - used; }
         *hole = make_ulonglong2(hs, hl);
     }
 }
@@ -290,6 +302,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
     if (threadIdx.x == 0) {
         bl.alloc_state = kAllocEmpty | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
         bl.defer_state = kAllocEmpty | kDeferChunk;
+        bl.chunk_shift = chunk_shift_of(kChunkRecords);
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
 // inline and emitted through the same allocator (its blocks add their own holes to the list k_fixup closes).
 constexpr uint32_t kDeferBlocks = 384;       // fills the chip at this kernel's 3 waves per SIMD when the list is long
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms in, const DevParams *dprm, Sorted so, EmitTarget tg,
-                                                                         ulonglong2 *hole_list, unsigned long long *result) {
+                                                                         ulonglong2 *hole_list, unsigned long long *result, uint32_t chunk_shift) {
     __shared__ LdsParams prm;
     __shared__ WaveLds<kEmit> wl[kWavesPerBlock];
     __shared__ BlockLds bl;
@@ -455,8 +468,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_pairs_deferred(DevAtoms
     }
     load_lds_params(prm, dprm, nullptr);
     if (threadIdx.x == 0) {
-        bl.alloc_state = kAllocEmpty | kChunkRecords;
+        bl.alloc_state = kAllocEmpty | (1u << chunk_shift);  // (the chunk size of the emit kernel that ran before: one counter, one unit)
         bl.defer_state = kAllocEmpty | kDeferChunk;
+        bl.chunk_shift = chunk_shift;
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -517,7 +531,7 @@ DEVFN unsigned long long scan1024_u64(unsigned long long v, unsigned long long *
 // no_deferred_pass: the launcher skipped k_pairs_deferred because the previous call on the same arrays deferred nothing (engine.cpp,
 // "deferred-pass memo"); if this call did defer candidates after all, status bit 128 makes the host repeat it with the pass.
 __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_list, uint32_t n_holes, const GridParams *g, EmitTarget tg,
-                                                       unsigned long long *result, uint32_t no_deferred_pass) {
+                                                       unsigned long long *result, uint32_t no_deferred_pass, uint32_t chunk_shift) {
     __shared__ unsigned long long fstart[kMaxHoles], fpre[kMaxHoles + 1];  // hole parts below P, any order
     __shared__ unsigned long long tpre[kMaxHoles + 1];                     // valid stretch of each chunk of [P, R) ...
     __shared__ unsigned int tlen[kMaxHoles];                               // ... and its length
@@ -525,19 +539,20 @@ __global__ __launch_bounds__(kFixThreads) void k_fixup(const ulonglong2 *hole_li
     const uint32_t i = threadIdx.x, e0 = 2u * i, e1 = e0 + 1u;
     const ulonglong2 h0 = (e0 < n_holes) ? hole_list[e0] : make_ulonglong2(0ull, 0ull);
     const ulonglong2 h1 = (e1 < n_holes) ? hole_list[e1] : make_ulonglong2(0ull, 0ull);
-    const unsigned long long R = result[2] * kChunkRecords;
+    const uint32_t sh = chunk_shift;  // records per chunk = 1 << sh (what the emit kernels of this launch sequence allocated in)
+    const unsigned long long R = result[2] << sh;
     unsigned long long holes_total;
     scan1024_u64(h0.y + h1.y, red, &holes_total);
     const unsigned long long P = R - holes_total;
     // tail chunks: chunk c0 + e, valid part = [max(chunk base, P), chunk end) minus the chunk's hole (set below)
-    const unsigned long long c0 = P / kChunkRecords, n_tail = R / kChunkRecords - c0;  // n_tail <= n_holes + 1 <= kMaxHoles
-    auto tail_start = [&](unsigned long long e) { const unsigned long long cb = (c0 + e) * kChunkRecords; return cb > P ? cb : P; };
-    tlen[e0] = (e0 < n_tail) ? (unsigned int)((c0 + e0 + 1) * kChunkRecords - tail_start(e0)) : 0u;
-    tlen[e1] = (e1 < n_tail) ? (unsigned int)((c0 + e1 + 1) * kChunkRecords - tail_start(e1)) : 0u;
+    const unsigned long long c0 = P >> sh, n_tail = (R >> sh) - c0;  // n_tail <= n_holes + 1 <= kMaxHoles
+    auto tail_start = [&](unsigned long long e) { const unsigned long long cb = (c0 + e) << sh; return cb > P ? cb : P; };
+    tlen[e0] = (e0 < n_tail) ? (unsigned int)(((c0 + e0 + 1) << sh) - tail_start(e0)) : 0u;
+    tlen[e1] = (e1 < n_tail) ? (unsigned int)(((c0 + e1 + 1) << sh) - tail_start(e1)) : 0u;
     __syncthreads();
     auto cut = [&](const ulonglong2 &h) {  // a hole cuts the end off one tail chunk
-        if (h.y && h.x / kChunkRecords >= c0) {
-            const unsigned long long j = h.x / kChunkRecords - c0, ts = tail_start(j);
+        if (h.y && (h.x >> sh) >= c0) {
+            const unsigned long long j = (h.x >> sh) - c0, ts = tail_start(j);
             tlen[j] = h.x > ts ? (unsigned int)(h.x - ts) : 0u;
         }
     };
@@ -701,17 +716,19 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 // what follows either emit kernel: the deferred probe pass (unless the engine's memo says this input defers nothing) and the hole fix-up
 // patch: the emit kernel wrote the deferred candidates as records with a placeholder kind (k_emit, all candidates): k_patch_deferred decides
 // the kinds in place; otherwise k_pairs_deferred classifies and emits them itself (its blocks add holes of their own)
-static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const EmitTarget &tg, uint32_t nb, hipStream_t st, Profiler *prof, bool skip_deferred, bool patch) {
+static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const EmitTarget &tg, uint32_t nb, hipStream_t st, Profiler *prof, bool skip_deferred, bool patch,
+                             uint32_t chunk_records) {
+    const uint32_t chunk_shift = chunk_shift_of(chunk_records);
     if (prof) prof->end(st);
     if (!skip_deferred) {
         if (prof) prof->begin("pairs_deferred", st);
         if (patch) hipLaunchKernelGGL(k_patch_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.result);
-        else hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result);
+        else hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result, chunk_shift);
         if (prof) prof->end(st);
     }
     if (prof) prof->begin("pairs_fixup", st);
     hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, (skip_deferred || patch) ? nb : nb + kDeferBlocks,
-                       (const GridParams *)ws.grid, tg, ws.result, skip_deferred ? 1u : 0u);
+                       (const GridParams *)ws.grid, tg, ws.result, skip_deferred ? 1u : 0u, chunk_shift);
     if (prof) prof->end(st);
 }
 void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
@@ -739,5 +756,5 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     hipLaunchKernelGGL((k_pairs<kEmit, false>), dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
                        (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,
                        ws.task_ctr, ws.result);
-    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, false);
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, false, kChunkRecords);
 }

@@ -150,7 +150,7 @@ DEVFN void lm_store_records(lmask m, uint4 *base, uint32_t byte_off, const u32x4
 // output positions are requested from the block's allocator as soon as the cutoff test is in -- the answer travels while the rows are
 // computed -- and a pair that needs a probe is written with kind 0 at its final position and listed {slots, position} for
 // k_patch_deferred (pairs.inl).
-template <bool FULL, bool ONLY>
+template <bool FULL, bool ONLY, uint32_t CHUNK>
 DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, const Sorted &so, uint32_t first, uint32_t count, uint32_t slot0,
                          const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
     first = __builtin_amdgcn_readfirstlane(first); count = __builtin_amdgcn_readfirstlane(count);  // (wave-uniform by construction: say so)
@@ -244,7 +244,7 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
     rec.z = __float_as_uint((float)y);
     if (!ONLY) {
         if (!n_early) return;
-        const Slots sl = alloc_finish<kChunkRecords>(bl.alloc_state, &result[2], n_early, lane, a_old);
+        const Slots sl = alloc_finish<CHUNK>(bl.alloc_state, &result[2], n_early, lane, a_old);
         const uint32_t rank = lm_rank(m_valid);
         if (m_defer) {  // rare: the probe pass patches these kinds in place
             const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], 2u * (uint32_t)__popcll(m_defer), lane);  // (even counts: a pair never straddles a chunk)
@@ -278,7 +278,7 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
     }
     const uint32_t n = (uint32_t)__popcll(m_valid);
     if (n) {  // compacted, coalesced store of the batch's records straight from registers
-        const Slots sl = alloc_chunked<kChunkRecords>(bl.alloc_state, &result[2], n, lane);
+        const Slots sl = alloc_chunked<CHUNK>(bl.alloc_state, &result[2], n, lane);
         const uint32_t rank = lm_rank(m_valid);
         if (sl.n0 == n && sl.pos0 + n <= tg.capacity) {  // one run inside the caller's buffer
             lm_store_records(m_valid, reinterpret_cast<uint4 *>(tg.out) + sl.pos0, rank << 4, rec);
@@ -296,13 +296,18 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
 template <int WAVES, int SPLIT, bool ONLY>
 __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
                                                                                            EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
+    // The 4-wave kernels serve inputs of a few thousand records per block, or a few hundred: a 4096-record chunk per block would leave
+    // holes as large as the list itself for the fix-up to close.  (Not smaller than this: every chunk costs a returning atomic on the one
+    // global counter, ~11 ns each when they queue up -- 256-record chunks on a 10^5-atom input made the kernel 2.4x slower.)
+    constexpr uint32_t kChunkE = WAVES == kEWaves ? kChunkRecords : (SPLIT == 8 ? kTinyChunkRecords : kSmallChunkRecords);
     __shared__ TablesE tb;
     __shared__ WaveLdsE wl[WAVES];
     __shared__ BlockLds bl;
     load_tables_e(tb, dprm);
     if (threadIdx.x == 0) {
-        bl.alloc_state = kAllocEmpty | kChunkRecords;  // "exhausted": the first allocation fetches a chunk
+        bl.alloc_state = kAllocEmpty | kChunkE;  // "exhausted": the first allocation fetches a chunk
         bl.defer_state = kAllocEmpty | kDeferChunk;
+        bl.chunk_shift = chunk_shift_of(kChunkE);
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -425,13 +430,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                         qbyte = qb;
                         if (qbyte < queue_lds + 256u) break;  // every test of the run is in the queue
                         qbyte -= 256u;                        // a full batch: the 64 entries at the tail
-                        exact_batch_e<true, ONLY>(K, tb, w, bl, so, (qbyte - queue_lds) >> 2, 64u, slot0, tg, result, lane, wflags, probe_bits);
+                        exact_batch_e<true, ONLY, kChunkE>(K, tb, w, bl, so, (qbyte - queue_lds) >> 2, 64u, slot0, tg, result, lane, wflags, probe_bits);
                     }
                     if (kSubs > 1u) { it0 += (kSubs - 1u) * kEAcc; more = __any(it0 < len); }
                 }
             }
         }
-        if (qbyte != queue_lds) exact_batch_e<false, ONLY>(K, tb, w, bl, so, 0u, (qbyte - queue_lds) >> 2, slot0, tg, result, lane, wflags, probe_bits);  // the home records go with the task: drain
+        if (qbyte != queue_lds) exact_batch_e<false, ONLY, kChunkE>(K, tb, w, bl, so, 0u, (qbyte - queue_lds) >> 2, slot0, tg, result, lane, wflags, probe_bits);  // the home records go with the task: drain
         uint32_t nxt_task = 0;
         if (lane == 0) nxt_task = atomicAdd(ctr, 1u);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);
@@ -462,6 +467,6 @@ void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
         else ARP_LAUNCH_E(kEWaves, 1, false);
     }
 #undef ARP_LAUNCH_E
-    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only);
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, tiny ? kTinyChunkRecords : (small ? kSmallChunkRecords : kChunkRecords));
 }
 static_assert(kEBlocks + 384u <= kMaxHoles && 1536u + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");
