@@ -289,17 +289,17 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
     }
 }
 
-// WAVES per block: kEWaves for inputs that fill the chip; 4 for small ones, whose few tasks then spread over more CUs
+// WAVES per block: kEWaves; 4 for the smallest inputs (below 320 tasks), whose few tasks then spread over more CUs
 // SPLIT: 1, or 4 = a task's five window kinds are shared out over four waves ({0, 1}, {2}, {3}, {4}), or 8 = two waves per kind set on
 // alternate 32-test runs: a small input has few tasks and each is a long chain of dependent round trips, so more waves on a
 // fraction of the chain each is what shortens the launch
 template <int WAVES, int SPLIT, bool ONLY>
 __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
                                                                                            EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
-    // The 4-wave kernels serve inputs of a few thousand records per block, or a few hundred: a 4096-record chunk per block would leave
+    // Inputs that do not fill the chip emit a few thousand records per block, or a few hundred: a 4096-record chunk per block would leave
     // holes as large as the list itself for the fix-up to close.  (Not smaller than this: every chunk costs a returning atomic on the one
-    // global counter, ~11 ns each when they queue up -- 256-record chunks on a 10^5-atom input made the kernel 2.4x slower.)
-    constexpr uint32_t kChunkE = WAVES == kEWaves ? kChunkRecords : (SPLIT == 8 ? kTinyChunkRecords : kSmallChunkRecords);
+    // global counter, ~11 ns each when they queue up -- 256-record chunks made the kernel 2.4x slower on 10^5 atoms and 30 % slower on 2x10^4.)
+    constexpr uint32_t kChunkE = SPLIT == 8 ? kTinyChunkRecords : (SPLIT == 4 ? kSmallChunkRecords : kChunkRecords);
     __shared__ TablesE tb;
     __shared__ WaveLdsE wl[WAVES];
     __shared__ BlockLds bl;
@@ -449,24 +449,29 @@ void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
                    bool skip_deferred) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t tasks = (in.n + 63u) / 64u;
-    // few tasks: 4-wave blocks reach more CUs, and every task is shared out over four or eight waves (6bft: 128 tasks)
-    const bool small = tasks < 3072u, tiny = tasks < 768u;
-    const uint32_t split = tiny ? 8u : (small ? 4u : 1u);
-    const uint32_t per = small ? 4u : (uint32_t)kEWaves, cap = small ? 1536u : kEBlocks, want = (split * tasks + per - 1u) / per;
+    // Fewer tasks than the chip has wave slots: every task is shared out over four waves by window kind (eight for the smallest inputs, two
+    // per kind set), and below 320 tasks the blocks shrink to four waves so that the few tasks reach more CUs.  Thresholds from size sweeps
+    // of this kernel (tests/microbench/ab_r3ae.sh .. ab_r3ag.sh, profiles/r03_small_inputs.txt): a task is a chain of dependent round trips,
+    // and an input that does not fill the chip has nothing else to hide it behind.
+    const bool shared = tasks < 4608u, narrow = tasks < 320u, eight = tasks < 48u;
+    const uint32_t split = eight ? 8u : (shared ? 4u : 1u);
+    const uint32_t per = narrow ? 4u : (uint32_t)kEWaves, cap = narrow ? 1536u : kEBlocks, want = (split * tasks + per - 1u) / per;
     const uint32_t nb = want < 1 ? 1 : (want > cap ? cap : want);
     if (prof) prof->begin("pairs_emit", st);
 #define ARP_LAUNCH_E(W, S, O) hipLaunchKernelGGL((k_emit<W, S, O>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
                                                  (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
     if (contacts_only) {
-        if (small && split == 8u) ARP_LAUNCH_E(4, 8, true);
-        else if (small) ARP_LAUNCH_E(4, 4, true);
+        if (eight) ARP_LAUNCH_E(4, 8, true);
+        else if (narrow) ARP_LAUNCH_E(4, 4, true);
+        else if (shared) ARP_LAUNCH_E(kEWaves, 4, true);
         else ARP_LAUNCH_E(kEWaves, 1, true);
     } else {
-        if (small && split == 8u) ARP_LAUNCH_E(4, 8, false);
-        else if (small) ARP_LAUNCH_E(4, 4, false);
+        if (eight) ARP_LAUNCH_E(4, 8, false);
+        else if (narrow) ARP_LAUNCH_E(4, 4, false);
+        else if (shared) ARP_LAUNCH_E(kEWaves, 4, false);
         else ARP_LAUNCH_E(kEWaves, 1, false);
     }
 #undef ARP_LAUNCH_E
-    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, tiny ? kTinyChunkRecords : (small ? kSmallChunkRecords : kChunkRecords));
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, eight ? kTinyChunkRecords : (shared ? kSmallChunkRecords : kChunkRecords));
 }
 static_assert(kEBlocks + 384u <= kMaxHoles && 1536u + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");
