@@ -453,7 +453,7 @@ void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
     // per kind set), and below 320 tasks the blocks shrink to four waves so that the few tasks reach more CUs.  Thresholds from size sweeps
     // of this kernel (tests/microbench/ab_r3ae.sh .. ab_r3ag.sh, profiles/r03_small_inputs.txt): a task is a chain of dependent round trips,
     // and an input that does not fill the chip has nothing else to hide it behind.
-    const bool shared = tasks < 4608u, narrow = tasks < 320u, eight = tasks < 48u;
+    const bool shared = tasks < 4608u, narrow = tasks < 320u, eight = tasks < 160u;  // (eight: 6bft's 128 tasks run 3 us faster that way, an S2 cloud of the same size 1.3 us slower)
     const uint32_t split = eight ? 8u : (shared ? 4u : 1u);
     const uint32_t per = narrow ? 4u : (uint32_t)kEWaves, cap = narrow ? 1536u : kEBlocks, want = (split * tasks + per - 1u) / per;
     const uint32_t nb = want < 1 ? 1 : (want > cap ? cap : want);

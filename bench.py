@@ -182,7 +182,7 @@ def batch5k_share(aa, synth, sizes, mine, pool=48):
     return [made[min(picks, key=lambda q: (abs(int(sizes[q]) - int(sizes[k])), q))] for k in mine]
 
 
-def cpu_baseline(n_atoms: int, workload: str):
+def cpu_baseline(n_atoms: int, workload: str, seed: int = 0xBA5E, gpu_pairs=None):
     """The oracle ("port": this repo's C restatement, NOT the reference binary) on bounded samples: one thread on the headline
     cloud, then all host threads at once, each on its own independent 10^5-atom cloud (the reference's -j 0, utils.rs:8-30)."""
     import threading
@@ -191,7 +191,7 @@ def cpu_baseline(n_atoms: int, workload: str):
     import synth
 
     gen = getattr(synth, f"gen_{workload if workload in ('s1', 's2') else 's2'}")
-    rec = gen(n_atoms, seed=0xBA5E)
+    rec = gen(n_atoms, seed=seed)  # (the headline cloud itself when the sample has its size: the pair counts must then agree)
     s = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True)
     t0 = time.perf_counter()
     pairs = s.atomic_contacts("/", 0.1, 6.5)
@@ -224,6 +224,7 @@ def cpu_baseline(n_atoms: int, workload: str):
                       "sample": f"{threads} of {os.cpu_count()} host threads, each one independent 100000-atom cloud ({counts[0]} pairs), {dt_all:.1f} s"},
         "reference_toolchain": cargo or "cargo not found on this box: the reference (Rust) cannot be built or timed here",
         "note": "restatement CPU baseline (oracle/arp_oracle.c), not the reference binary",
+        **({"same_cloud_as_gpu": True, "pair_count_equals_gpu": bool(len(pairs) == gpu_pairs)} if gpu_pairs is not None else {}),
     }
 
 
@@ -411,7 +412,10 @@ def main():
         }
         line.update(sub)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_atoms, args.workload)
+            wl = args.workload if args.workload in ("s1", "s2") else "s2"
+            same = args.cpu_sample_atoms == args.atoms and args.workload in ("s1", "s2") and not os.environ.get("ARP_BENCH_ORDER")
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_atoms, wl, SEED + (4 if wl == "s2" else 3) if same else 0xBA5E,
+                                                n_pairs if same and not args.contacts_only else None)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
