@@ -542,6 +542,56 @@ def test_ordered_paths_on_a_fresh_context_and_after_a_workspace_regrow():
         assert_pairs_equal(c.atomic_contacts(big.view("/")), want_big, "single pass after regrow")
 
 
+def test_deferred_pass_memo_survives_new_content_in_the_same_buffers():
+    """The engine skips the launch of the probe pass when the previous call on the same (x pointer, n) deferred nothing; the fix-up checks
+    on the device that nothing was deferred THIS time and the host repeats the call with the pass otherwise.  Here the caller's device
+    buffers keep their addresses while their CONTENT alternates between a cloud that defers nothing and a hydrogen-rich structure of the
+    same size whose HydrogenBond / Disulfide kinds only the probe pass can decide -- every call must equal the oracle, whatever the memo
+    guessed (enqueue/result and the one-call form; all candidates and contacts only)."""
+    torch = pytest.importorskip("torch")
+    rec_b = synth.gen_stress(n_res=300, seed=17)
+    prod_b = aa.Structure.from_records(rec_b)
+    soa_b = prod_b.soa("/")
+    n = len(soa_b["x"])
+    rec_a = synth.gen_s2(n, seed=5)
+    prod_a = aa.Structure.from_records(rec_a, hierarchy=True)
+    soa_a = prod_a.soa("/")
+    assert len(soa_a["x"]) == n
+    want_a = ob.Structure.from_atoms(synth.records_to_oracle(rec_a, flat=True), flat=True).atomic_contacts()
+    want_b = ob.Structure.from_atoms(synth.records_to_oracle(rec_b, flat=False), flat=False).atomic_contacts()
+    probe_kinds = (1 << aa.INTERACTIONS.index("HydrogenBond")) | (1 << aa.INTERACTIONS.index("Disulfide"))
+    assert (want_b["kind"] & probe_kinds).any() and not (want_a["kind"] & probe_kinds).any()
+
+    def dev_of(v):
+        return torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda()
+
+    per_atom = ("x", "y", "z", "attr", "res_ord", "chain_rank", "model", "res_id")
+    shared = {k: torch.empty_like(dev_of(soa_b[k])) for k in per_atom}
+    keep = []
+    atoms, content = {}, {}
+    for name, soa in (("a", soa_a), ("b", soa_b)):
+        dev = dict(shared)
+        dev.update({k: dev_of(v) for k, v in soa.items() if k not in per_atom})
+        content[name] = {k: dev_of(soa[k]) for k in per_atom}
+        atoms[name] = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
+    assert atoms["a"].x == atoms["b"].x and atoms["a"].n == atoms["b"].n
+    want = {"a": want_a, "b": want_b}
+    c = aa.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    out = torch.empty((max(len(want_a), len(want_b)), 4), dtype=torch.int32, device="cuda")
+    for only in (False, True):
+        prm = aa.default_params(contacts_only=only)
+        for name in ("a", "a", "b", "b", "a", "b", "a", "a"):
+            for k in per_atom:
+                shared[k].copy_(content[name][k])
+            torch.cuda.synchronize()
+            w = want[name] if not only else want[name][want[name]["kind"] != 0]
+            c.enqueue(atoms[name], prm, out.data_ptr(), out.shape[0])
+            got_n = c.result()
+            assert got_n == len(w), f"{name} only={only}: {got_n} pairs vs oracle {len(w)}"
+            assert_pairs_equal(out[:got_n].cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1), w, f"memo {name} only={only} (enqueue)")
+            assert_pairs_equal(c.atomic_contacts(atoms[name], prm), w, f"memo {name} only={only} (one call)")
+
+
 def test_deferred_list_overflow_grows_and_repeats(monkeypatch):
     # hydrogen-rich structure: thousands of candidates need a probe; a 65536-entry list (every block holds a partly used 512-entry chunk) overflows and is grown 4x per retry
     rec = synth.gen_stress(n_res=600, seed=91)
