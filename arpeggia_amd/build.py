@@ -49,7 +49,7 @@ def needs_build() -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False, defines: tuple = (), out: Path | None = None) -> Path:
-    """defines/out: diagnostic builds only (e.g. -DARP_ABLATE=1 timing ablations, loaded through ARPEGGIA_AMD_LIB)."""
+    """defines/out: test-only builds (build_host_table_library: -DARP_WITH_HOST_TABLE), loaded through ARPEGGIA_AMD_LIB."""
     if not force and not defines and not needs_build():
         return LIB
     objs = []
