@@ -433,6 +433,28 @@ def test_contacts_only_is_the_kind_filter_of_the_full_list(ctx, source):
         assert_pairs_equal(out.cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1), want, f"{source} resident contacts-only det={det}")
 
 
+def test_packed_batch_of_thousands_of_tiny_structures(ctx):
+    """45 000 members of 3-9 residues each (packs of ~20 000: the 2^20-atom limit): a few dozen records per member, so that one wave's range of
+    a pack's joint list (a couple of hundred records) mentions more members than its table holds (batch.inl kSplitSlots) -- the per-64-records
+    part of the split -- and many members come back empty.  Every member against its single call, both modes; the single calls of the
+    distinct members against the oracle."""
+    base = [synth.gen_stress(n_res=3 + k % 7, seed=300 + k, hydrogens=bool(k % 2), n_chains=1 + k % 2) for k in range(40)]
+    structs = [aa.Structure.from_records(r) for r in base]
+    order = np.random.default_rng(3).integers(0, len(structs), 45000)
+    views = [structs[k].view("/") for k in order]
+    for only in (False, True):
+        prm = aa.default_params(contacts_only=only)
+        singles = [ctx.atomic_contacts(structs[k].view("/"), prm) for k in range(len(structs))]
+        for k in range(len(structs)):
+            want = ob.Structure.from_atoms(synth.records_to_oracle(base[k], flat=False), flat=False).atomic_contacts()
+            assert_pairs_equal(singles[k], want[want["kind"] != 0] if only else want, f"tiny member {k} only={only}")
+        got = aa.atomic_contacts_batch([ctx], views, prm)
+        assert len(got) == len(views)
+        assert sum(len(g) for g in got) == sum(len(singles[k]) for k in order)
+        for j, k in enumerate(order):
+            assert np.array_equal(canon(got[j]), canon(singles[k])), (j, int(k), only)
+
+
 def test_packed_batch_reports_the_failing_structure(ctx):
     ok = synth.gen_stress(n_res=60, seed=21, hydrogens=False)
     bad = {k: v[:4].copy() for k, v in ok.items()}
