@@ -198,7 +198,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     return ARP_OK;
 }
 
-extern "C" arp_status arp_context_create(int32_t device, arp_context **out) {
+extern "C" arp_status arp_context_create(int32_t device, arp_context **out) try {
     if (!out) { set_error("null out"); return ARP_ERR_BAD_INPUT; }
     *out = nullptr;
     int cnt = arp_device_count();
@@ -218,7 +218,7 @@ extern "C" arp_status arp_context_create(int32_t device, arp_context **out) {
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
 static void free_staged(arp_context *ctx) {
     auto &s = ctx->st;
@@ -428,7 +428,7 @@ static arp_status grow_defer_list(arp_context *ctx, uint64_t n) {
 
 // ---- the hot path ----------------------------------------------------------------------------------------------
 extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, arp_pair *out,
-                                                  uint64_t capacity) {
+                                                  uint64_t capacity) try {
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
     if ((s = validate(atoms, params)) != ARP_OK) return s;
@@ -456,9 +456,9 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
     ctx->last_atoms = *atoms; ctx->last_out = out;  // (device pointers: the caller keeps them alive until arp_contacts_atomic_result)
     ctx->pending = true;
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
-extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs) {
+extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs) try {
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
     if (!ctx->pending) { set_error("no enqueued call"); return ARP_ERR_BAD_INPUT; }
@@ -484,7 +484,7 @@ extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_p
         return ARP_ERR_CAPACITY;
     }
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
 // Single-pass emitter into the context's reusable device buffer: ONE pass -- no count pass, no hipMalloc/hipFree per call (together
 // ~half of the latency of a PDB-sized structure).  A buffer that turns out too small only makes the pass report the size (k_fixup);
@@ -548,13 +548,13 @@ arp_status arp::contacts_atomic_view(arp_context *ctx, const arp_atoms *atoms, c
 
 static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location, arp_pairs *out);
 extern "C" arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location,
-                                          arp_pairs *out) {
+                                          arp_pairs *out) try {
     for (;;) {
         arp_status s = contacts_atomic_once(ctx, atoms, params, out_location, out);
         if (s != kRetryDefer) return s;
         if ((s = grow_defer_list(ctx, atoms->n)) != ARP_OK) return s;  // like the pair buffer: grow, repeat the pass
     }
-}
+} ARP_ABI_CATCH
 static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms, const arp_params *params, int32_t out_location, arp_pairs *out) {
     if (!out) { set_error("null out"); return ARP_ERR_BAD_INPUT; }
     out->n = 0; out->data = nullptr; out->location = out_location;
@@ -923,7 +923,7 @@ arp_status finalize_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp
 }  // namespace
 
 extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms, int32_t n_structures,
-                                                const arp_params *params, arp_pairs *outs) {
+                                                const arp_params *params, arp_pairs *outs) try {
     if (!ctxs || n_ctx <= 0 || !atoms || n_structures < 0 || !outs || !params) { set_error("bad batch arguments"); return ARP_ERR_BAD_INPUT; }
     for (int32_t k = 0; k < n_structures; k++) outs[k] = arp_pairs{0, nullptr, ARP_MEM_HOST, 0};
     for (int32_t k = 0; k < n_structures; k++)
@@ -1006,7 +1006,7 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
             return st[d];
         }
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
 // ---- SAP neighbour sum (reference src/sap.rs:155-204) ---------------------------------------------------
 extern "C" float arp_sap_weight(const char *resn, float sasa) {
@@ -1027,7 +1027,7 @@ extern "C" float arp_sap_weight(const char *resn, float sasa) {
 }
 
 extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const double *x, const double *y, const double *z, const uint8_t *sidechain,
-                                           const float *weight, float sap_radius, float *out) {
+                                           const float *weight, float sap_radius, float *out) try {
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
     if (n && (!x || !y || !z || !sidechain || !weight || !out)) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
@@ -1068,7 +1068,7 @@ extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const d
     }
     memcpy(out, h_out, n * 4);
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
 // ---- accessors for the table path (table_dev.hip) ---------------------------------------------------------------------------
 namespace arp {

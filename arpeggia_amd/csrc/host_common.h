@@ -3,8 +3,11 @@
 #include <array>
 #include <cstdarg>
 #include <cstdint>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -13,6 +16,13 @@
 namespace arp {
 
 void set_error(const char *fmt, ...);
+
+// No exception may cross the C ABI (SURVEY.md 8b "Errors": the reference panics, a C boundary returns a status).  Every status-returning entry
+// point that allocates or starts threads is a function-try-block that ends in this: `extern "C" arp_status f(...) try { ... } ARP_ABI_CATCH`.
+#define ARP_ABI_CATCH                                                                                                               \
+    catch (const std::bad_alloc &) { arp::set_error("out of host memory"); return ARP_ERR_OOM; }                                   \
+    catch (const std::exception &e_) { arp::set_error("internal error: %s", e_.what()); return ARP_ERR_HIP; }                       \
+    catch (...) { arp::set_error("internal error: unknown exception"); return ARP_ERR_HIP; }
 
 // Fixed-width, NUL-padded string column (n x W chars), the layout the C ABI hands to numpy / Rust.
 template <int W>
@@ -103,7 +113,12 @@ void parallel_for(size_t n, size_t min_per_worker, F &&fn) {
     if (workers <= 1) { fn((size_t)0, n, (size_t)0); return; }
     std::vector<std::thread> th;
     th.reserve(workers);
-    for (size_t w = 0; w < workers; w++) th.emplace_back([&, w]() { fn(n * w / workers, n * (w + 1) / workers, w); });
+    size_t started = 0;  // slices [0, started) run on threads of their own; the caller takes the last one and any that could not get a thread
+    for (; started + 1 < workers; started++) {
+        const size_t w = started;
+        try { th.emplace_back([&, w]() { fn(n * w / workers, n * (w + 1) / workers, w); }); } catch (const std::system_error &) { break; }
+    }
+    for (size_t w = started; w < workers; w++) fn(n * w / workers, n * (w + 1) / workers, w);
     for (auto &t : th) t.join();
 }
 }  // namespace arp

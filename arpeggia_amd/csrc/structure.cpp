@@ -621,7 +621,7 @@ extern "C" int32_t arp_element_class(const char *symbol) {
     return element_class(s.c_str());
 }
 
-extern "C" arp_status arp_structure_load(const char *path, int32_t ignore_zero_occupancy, arp_structure **out) {
+extern "C" arp_status arp_structure_load(const char *path, int32_t ignore_zero_occupancy, arp_structure **out) try {
     if (!path || !out) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     *out = nullptr;
     std::vector<Record> recs;
@@ -640,9 +640,9 @@ extern "C" arp_status arp_structure_load(const char *path, int32_t ignore_zero_o
     if (st != ARP_OK) { delete s; return st; }
     *out = s;
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
-extern "C" arp_status arp_structure_from_records(const arp_records *rec, int32_t hierarchy, arp_structure **out) {
+extern "C" arp_status arp_structure_from_records(const arp_records *rec, int32_t hierarchy, arp_structure **out) try {
     if (!rec || !out) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     *out = nullptr;
     if (rec->n && (!rec->x || !rec->y || !rec->z || !rec->serial || !rec->resi || !rec->name || !rec->resn || !rec->chain || !rec->element)) {
@@ -671,12 +671,12 @@ extern "C" arp_status arp_structure_from_records(const arp_records *rec, int32_t
     if (st != ARP_OK) { delete s; return st; }
     *out = s;
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
 extern "C" void arp_structure_free(arp_structure *s) { delete s; }
 extern "C" uint64_t arp_structure_n_atoms(const arp_structure *s) { return s ? s->n : 0; }
 
-extern "C" arp_status arp_structure_atoms(arp_structure *s, const char *groups, arp_atoms *v) {
+extern "C" arp_status arp_structure_atoms(arp_structure *s, const char *groups, arp_atoms *v) try {
     if (!s || !v) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     arp_status st = apply_groups(s, groups);
     if (st != ARP_OK) return st;
@@ -689,7 +689,7 @@ extern "C" arp_status arp_structure_atoms(arp_structure *s, const char *groups, 
     v->res_h_ptr = s->res_h_ptr.data(); v->res_h_idx = s->res_h_idx.data(); v->res_cb = s->res_cb.data(); v->res_sg = s->res_sg.data();
     v->location = ARP_MEM_HOST;
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
 extern "C" const char *arp_structure_strings(const arp_structure *s, const char *column, int32_t *width) {
     if (!s || !column) return nullptr;

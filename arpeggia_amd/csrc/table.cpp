@@ -422,7 +422,7 @@ TableCache *table_cache_of(arp_structure *s) {
         const int workers = host_threads();
         const arp_structure *sp = s;
         const TableCache *cp = c;
-        c->book_job = std::thread([bk, sp, cp, workers]() {
+        auto fill = [bk, sp, cp, workers]() {
             HostThreadsScope scope(workers);
             const size_t n_atoms = sp->n;
             auto lens_of = [](const EntityRec &e) {
@@ -446,7 +446,8 @@ TableCache *table_cache_of(arp_structure *s) {
                 e.resi = r.resi; e.atomi = 0; e.atom = -1; e.model = (uint32_t)r.model_serial;
                 bk->lens[n_atoms + k] = lens_of(e);
             }
-        });
+        };
+        try { c->book_job = std::thread(fill); } catch (const std::system_error &) { fill(); }  // (no thread to be had: filled here)
     }
     lap("entity book (job started)");
     s->table_cache = c; s->table_cache_free = free_table_cache;
@@ -636,7 +637,7 @@ extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const
 }
 
 extern "C" arp_status arp_get_contacts_mt(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp, double dist_cutoff,
-                                          int32_t num_threads, arp_table **out) {
+                                          int32_t num_threads, arp_table **out) try {
     if (!s || !out || !groups) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     *out = nullptr;
     HostThreadsScope threads(num_threads);  // one worker count for every pass of this call
@@ -644,12 +645,12 @@ extern "C" arp_status arp_get_contacts_mt(arp_context *ctx, arp_structure *s, co
     if (getenv("ARP_TABLE_HOST") != nullptr) return get_contacts_host(ctx, s, groups, vdw_comp, dist_cutoff, out);
 #endif
     return get_contacts_device(ctx, s, groups, vdw_comp, dist_cutoff, out);
-}
+} ARP_ABI_CATCH
 
 // The planes the device fits (residues.rs:270-298), per residue of the filtered model in hierarchy order: 12 doubles
 // {ring centre, ring normal, sc centre, sc normal}; valid[r] bit 1 = ring plane, bit 2 = side-chain plane.
 extern "C" uint64_t arp_structure_n_residues(const arp_structure *s) { return s ? s->residues.size() : 0; }
-extern "C" arp_status arp_structure_fit_planes(arp_context *ctx, arp_structure *s, double *planes, uint8_t *valid) {
+extern "C" arp_status arp_structure_fit_planes(arp_context *ctx, arp_structure *s, double *planes, uint8_t *valid) try {
     if (!ctx || !s || !planes || !valid) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     arp_atoms view;
     arp_status st = arp_structure_atoms(s, s->groups_valid ? s->groups_applied.c_str() : "/", &view);
@@ -662,7 +663,7 @@ extern "C" arp_status arp_structure_fit_planes(arp_context *ctx, arp_structure *
     memcpy(planes, p.data(), p.size() * sizeof(double));
     memcpy(valid, v.data(), v.size());
     return ARP_OK;
-}
+} ARP_ABI_CATCH
 
 extern "C" void arp_table_free(arp_table *t) { delete t; }
 extern "C" uint64_t arp_table_rows(const arp_table *t) { return t ? t->n : 0; }
@@ -895,7 +896,7 @@ arp_status export_arrow_fast(const arp_table *t, ArrowArray *out_array, ArrowSch
 }
 }  // namespace
 
-extern "C" arp_status arp_table_export_arrow(const arp_table *t, ArrowArray *out_array, ArrowSchema *out_schema) {
+extern "C" arp_status arp_table_export_arrow(const arp_table *t, ArrowArray *out_array, ArrowSchema *out_schema) try {
     if (!t || !out_array || !out_schema) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
     if (t->n > 0x7FFFFFF0ull) { set_error("table too large for 32-bit utf8 offsets"); return ARP_ERR_BAD_INPUT; }
     if (t->book) return export_arrow_fast(t, out_array, out_schema);
@@ -971,4 +972,4 @@ extern "C" arp_status arp_table_export_arrow(const arp_table *t, ArrowArray *out
     out_schema->n_children = (int64_t)fields.size(); out_schema->children = f->kid_ptrs.data(); out_schema->dictionary = nullptr;
     out_schema->release = release_fields; out_schema->private_data = f;
     return ARP_OK;
-}
+} ARP_ABI_CATCH
