@@ -131,6 +131,7 @@ def _load():
         "arp_contacts_atomic_enqueue": (C.c_int32, [vp, C.POINTER(arp_atoms), C.POINTER(arp_params), vp, C.c_uint64]),
         "arp_contacts_atomic_result": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
         "arp_contacts_atomic_batch": (C.c_int32, [C.POINTER(vp), C.c_int32, C.POINTER(C.POINTER(arp_atoms)), C.c_int32, C.POINTER(arp_params), C.POINTER(arp_pairs)]),
+        "arp_release_host_pool": (C.c_uint64, []),
         "arp_sap_weight": (C.c_float, [C.c_char_p, C.c_float]),
         "arp_sap_neighbor_sum": (C.c_int32, [vp, C.c_uint64, _dp, _dp, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]),
         "arp_profile_enable": (C.c_int32, [vp, C.c_int32]),

@@ -655,6 +655,18 @@ std::shared_ptr<char> arp::pinned_block(size_t bytes) {
     return std::shared_ptr<char>(b->pinned, [b](char *) { std::lock_guard<std::mutex> lk(g_shared_mu); shared_release(b); });
 }
 
+extern "C" uint64_t arp_release_host_pool(void) {
+    std::vector<SharedBlock *> idle;
+    {
+        std::lock_guard<std::mutex> lk(g_shared_mu);
+        idle.swap(g_shared_pool);
+        g_shared_pool_bytes = 0;
+    }
+    uint64_t bytes = 0;
+    for (SharedBlock *b : idle) { bytes += b->cap; (void)hipHostFree(b->pinned); delete b; }
+    return bytes;
+}
+
 extern "C" void arp_pairs_free(arp_pairs *pairs) {
     if (!pairs || !pairs->data) return;
     if (pairs->location == ARP_MEM_DEVICE) (void)hipFree(pairs->data);

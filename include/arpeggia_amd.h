@@ -161,6 +161,10 @@ arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs);
  * goes back to a pool when its last list is freed; do not free() the pointers yourself. */
 arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms,
                                      int32_t n_structures, const arp_params *params, arp_pairs *outs);
+/* Pinned host blocks whose last pair list or table has been freed are kept for the next batch / table (pinning memory costs far more than
+ * the copy it saves; at most 6 GiB stay pooled).  This returns the idle ones to the system; blocks still referenced are untouched.
+ * Returns the number of bytes released. */
+uint64_t arp_release_host_pool(void);
 
 /* ---- SAP neighbour sum: the radius sum of src/sap.rs:155-204 on the same cell list ----
  * out[i] = sum over the atoms j with sidechain[j] != 0 and |r_j - r_i|^2 <= f64(sap_radius * sap_radius) (inclusive, i itself included) of

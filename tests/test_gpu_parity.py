@@ -363,6 +363,10 @@ def test_batch_of_structures(ctx):
         got = np.frombuffer(buf, dtype=aa.PAIR_DTYPE).copy()
         _lib.lib.arp_pairs_free(C.byref(outs[k]))
         assert np.array_equal(canon(got), canon(singles[k]))
+    # the members' lists were views into pooled pinned blocks: all freed now, so the pool holds idle blocks that can be given back
+    assert _lib.lib.arp_release_host_pool() > 0 and _lib.lib.arp_release_host_pool() == 0
+    again = aa.atomic_contacts_batch([ctx], views, prm)
+    assert all(np.array_equal(canon(again[k]), canon(singles[k])) for k in range(len(views)))
 
 
 def test_packed_batch_equals_single_calls(ctx):
