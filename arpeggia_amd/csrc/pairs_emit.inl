@@ -83,9 +83,13 @@ DEVFN void load_tables_e(TablesE &tb, const DevParams *dprm) {
 DEVFN void compact_rounds_e(uint32_t &mask, uint32_t tag, uint32_t &qbyte, uint32_t qfull) {
     unsigned long long save;
     uint32_t t, lz, ent, bm, c;
+    // Round 4: v_cmpx narrows exec itself, round after round (a lane whose mask has run empty stays out: its mask stays empty), so the loop
+    // carries no exec save / restore -- 5 scalar instructions per round instead of 7, each a 4-cycle slot of the SIMD's scalar issue
+    // (tests/microbench/issue_mix.hip).  exec is restored once, on the way out.
     asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
         "1:\n\t"
-        "v_cmp_ne_u32 vcc, 0, %[mask]\n\t"
+        "v_cmpx_ne_u32_e32 vcc, 0, %[mask]\n\t"
         "s_cbranch_vccz 2f\n\t"
         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
@@ -94,14 +98,13 @@ DEVFN void compact_rounds_e(uint32_t &mask, uint32_t tag, uint32_t &qbyte, uint3
         "v_add_u32 %[ent], %[tag], %[lz]\n\t"
         "v_lshrrev_b32 %[bm], %[lz], %[top]\n\t"
         "s_bcnt1_i32_b64 %[c], vcc\n\t"
-        "s_and_saveexec_b64 %[save], vcc\n\t"
         "ds_write_b32 %[t], %[ent]\n\t"
         "v_xor_b32 %[mask], %[mask], %[bm]\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
         "s_lshl2_add_u32 %[qb], %[c], %[qb]\n\t"
         "s_cmp_lt_u32 %[qb], %[qf]\n\t"
         "s_cbranch_scc1 1b\n\t"
-        "2:"
+        "2:\n\t"
+        "s_mov_b64 exec, %[save]"
         : [mask] "+v"(mask), [qb] "+s"(qbyte), [t] "=&v"(t), [lz] "=&v"(lz), [ent] "=&v"(ent), [bm] "=&v"(bm), [c] "=&s"(c), [save] "=&s"(save)
         : [tag] "v"(tag), [top] "s"(0x80000000u), [qf] "s"(qfull)
         : "vcc", "scc", "memory");
@@ -114,19 +117,22 @@ DEVFN double words_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)
 // Lane predicates as 64-bit scalar masks.  Left to the compiler, a predicate that is combined, balloted and branched on goes through
 // v_cndmask 0/1 + v_cmp_ne round trips (two vector instructions and a hazard nop per use); as a scalar value it is combined on the
 // scalar unit and only meets the vector pipe again as the condition of a select or as the exec mask of a store.
+// Round 4: the compares write their scalar register pair directly (VOP3 form).  tests/microbench/issue_mix.hip: a scalar instruction
+// holds the SIMD's scalar slot for 4 cycles -- as long as a half-rate vector instruction -- so the vcc + s_mov_b64 form of round 3 paid
+// one such slot per mask for nothing.
 typedef unsigned long long lmask;
 #define ARP_LMASK_CMP(NAME, OP, TA, CA, TB, CB)                                                                  \
     DEVFN lmask NAME(TA a, TB b) {                                                                               \
         lmask m;                                                                                                 \
-        asm(OP " vcc, %1, %2\n\ts_mov_b64 %0, vcc" : "=s"(m) : CA(a), CB(b) : "vcc");                            \
+        asm(OP "_e64 %0, %1, %2" : "=s"(m) : CA(a), CB(b));                                                      \
         return m;                                                                                                \
     }
-ARP_LMASK_CMP(lm_ge_f64_sv, "v_cmp_ge_f64_e32", double, "s", double, "v")      // a (scalar) >= b
-ARP_LMASK_CMP(lm_lt_u32_sv, "v_cmp_lt_u32_e32", uint32_t, "s", uint32_t, "v")  // a (scalar) <  b
-ARP_LMASK_CMP(lm_gt_u32_sv, "v_cmp_gt_u32_e32", uint32_t, "s", uint32_t, "v")  // a (scalar) >  b
-ARP_LMASK_CMP(lm_ne_u32, "v_cmp_ne_u32_e32", uint32_t, "v", uint32_t, "v")
-ARP_LMASK_CMP(lm_lt_u32_vv, "v_cmp_lt_u32_e32", uint32_t, "v", uint32_t, "v")  // a < b
-ARP_LMASK_CMP(lm_lt_u64, "v_cmp_lt_u64_e32", unsigned long long, "v", unsigned long long, "v")
+ARP_LMASK_CMP(lm_ge_f64_sv, "v_cmp_ge_f64", double, "s", double, "v")      // a (scalar) >= b
+ARP_LMASK_CMP(lm_lt_u32_sv, "v_cmp_lt_u32", uint32_t, "s", uint32_t, "v")  // a (scalar) <  b
+ARP_LMASK_CMP(lm_gt_u32_sv, "v_cmp_gt_u32", uint32_t, "s", uint32_t, "v")  // a (scalar) >  b
+ARP_LMASK_CMP(lm_ne_u32, "v_cmp_ne_u32", uint32_t, "v", uint32_t, "v")
+ARP_LMASK_CMP(lm_lt_u32_vv, "v_cmp_lt_u32", uint32_t, "v", uint32_t, "v")  // a < b
+ARP_LMASK_CMP(lm_lt_u64, "v_cmp_lt_u64", unsigned long long, "v", unsigned long long, "v")
 #undef ARP_LMASK_CMP
 DEVFN uint32_t lm_select(lmask m, uint32_t if_set, uint32_t if_clear) {
     uint32_t d;
@@ -135,6 +141,11 @@ DEVFN uint32_t lm_select(lmask m, uint32_t if_set, uint32_t if_clear) {
 }
 DEVFN bool lm_lane(lmask m, uint32_t lane) { return (m >> lane) & 1ull; }  // (rare paths only: a 64-bit vector shift)
 DEVFN uint32_t lm_rank(lmask m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+DEVFN uint32_t lm_count(lmask m) {  // (as asm: the builtin popcount of an asm-produced mask comes back through a vector register)
+    uint32_t c;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(c) : "s"(m) : "scc");
+    return c;
+}
 // one 16-byte non-temporal record store per lane of m: scalar base + 32-bit lane offset (store_record, pairs.inl)
 DEVFN void lm_store_records(lmask m, uint4 *base, uint32_t byte_off, const u32x4 &rec) {
     lmask save;
@@ -142,23 +153,46 @@ DEVFN void lm_store_records(lmask m, uint4 *base, uint32_t byte_off, const u32x4
                  : "=&s"(save) : "s"(m), "v"(byte_off), "v"(rec), "s"(base) : "memory");
 }
 
-// Phase 2 on queue entries [first, first + count), count <= 64 (FULL: count == 64): home operands out of LDS, neighbour operands gathered
-// (40 of the 48 bytes of the exact record).  Every lane computes everything -- the lanes beyond count on entry 0 (home lane 0, slot 0: in
-// bounds) -- and only the stores are predicated.
+// The block allocator's common case without the compiler's help (round 3's form cost ~25 scalar instructions per batch: 64-bit
+// sign-extension of the two readfirstlanes, selects, a loop header).  alloc_issue_e: lane 0 adds n to the block's LDS word {chunk << 32 |
+// records used} -- exec is narrowed to lane 0 around the one instruction; the answer stays in lane 0's registers until alloc_take_e reads it.
+DEVFN u32x2 alloc_issue_e(unsigned long long &state, uint32_t n) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)&state;
+    u32x2 old, add = {n, 0u};
+    lmask save;
+    asm volatile("s_and_saveexec_b64 %1, 1\n\tds_add_rtn_u64 %0, %2, %3\n\ts_mov_b64 exec, %1" : "=&v"(old), "=&s"(save) : "v"(addr), "v"(add) : "memory");
+    return old;
+}
+DEVFN unsigned long long u64_of(const u32x2 &v) { return ((unsigned long long)v.y << 32) | v.x; }
+// the general placement of a batch's records: the run may cross a chunk end or the end of the caller's buffer (scratch until k_fixup)
+DEVFN void store_batch_general(const Slots &sl, lmask m_valid, uint32_t n_rec, uint32_t rank, const u32x4 &rec, const EmitTarget &tg, unsigned long long *result,
+                               uint32_t lane) {
+    if (sl.n0 == n_rec && sl.pos0 + n_rec <= tg.capacity) {
+        lm_store_records(m_valid, reinterpret_cast<uint4 *>(tg.out) + sl.pos0, rank << 4, rec);
+    } else if (lm_lane(m_valid, lane)) {
+        uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
+        if (d) store_record(d, make_uint4(rec.x, rec.y, rec.z, rec.w));
+    }
+}
+
+// Phase 2 on the 64 queue entries that start at byte `qoff` of the wave's queue (FULL) or on its first `count` < 64 entries (!FULL, qoff = 0):
+// home operands out of LDS, neighbour operands gathered (40 of the 48 bytes of the exact record).  Every lane computes everything -- the
+// lanes beyond count on entry 0 (home lane 0, slot 0: in bounds) -- and only the stores are predicated.
 // ONLY = ARP_FLAG_CONTACTS_ONLY: candidates without a row are dropped, so a record's place is only known once its rows are; the pairs
 // a probe has to decide go to k_pairs_deferred, which emits them itself.  All candidates (!ONLY): every candidate is a record, so the
 // output positions are requested from the block's allocator as soon as the cutoff test is in -- the answer travels while the rows are
 // computed -- and a pair that needs a probe is written with kind 0 at its final position and listed {slots, position} for
 // k_patch_deferred (pairs.inl).
+// Round 4 (scalar diet): one rare-path branch for "a probe decides" and "the square root needs the exact routine" together, the
+// allocator's common case in ~10 scalar instructions (alloc_take_e), masks straight out of the compares.
 template <bool FULL, bool ONLY, uint32_t CHUNK>
-DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, const Sorted &so, uint32_t first, uint32_t count, uint32_t slot0,
-                         const EmitTarget &tg, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
-    first = __builtin_amdgcn_readfirstlane(first); count = __builtin_amdgcn_readfirstlane(count);  // (wave-uniform by construction: say so)
+DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, const Sorted &so, uint32_t qoff, uint32_t count, uint32_t slot0,
+                         const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
+    qoff = __builtin_amdgcn_readfirstlane(qoff); count = __builtin_amdgcn_readfirstlane(count);  // (wave-uniform by construction: say so)
     wave_lds_fence();  // lanes read entries other lanes wrote
-    uint32_t e = w.queue[first + lane];
+    uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(w.queue) + qoff + 4u * lane);
     if (!FULL) e = lane < count ? e : 0u;
     wave_lds_fence();
-    const lmask m_act = FULL ? ~0ull : ((1ull << (count & 63u)) - 1ull);  // (!FULL: count < 64)
     const uint32_t hl = e >> kESlotBits, nb = e & kESlotMask;
     uint32_t goff;  // 48 nb as two full-rate instructions (fat_at, pairs.inl)
     asm("v_lshl_add_u32 %0, %1, 1, %1\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(goff) : "v"(nb));
@@ -191,10 +225,14 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
         const lmask o2 = same_model & bL & aR & ((same_chain & ba_chain) | (~same_chain & ba_cross));
         m_ok = o1 | o2; m_swap = o2 & ~o1;
     }
-    lmask m_valid = m_act & lm_ge_f64_sv(K.r2, s) & m_ok;  // rstar: inclusive
-    const uint32_t n_early = ONLY ? 0u : (uint32_t)__popcll(m_valid);
-    unsigned long long a_old = 0ull;
-    if (!ONLY && n_early) a_old = alloc_issue(bl.alloc_state, n_early, lane);
+    lmask m_valid = lm_ge_f64_sv(K.r2, s) & m_ok;  // rstar: inclusive
+    if (!FULL) m_valid &= (1ull << (count & 63u)) - 1ull;  // (!FULL: count < 64)
+    uint32_t n_rec = ONLY ? 0u : lm_count(m_valid);
+    u32x2 a_old = {0u, 0u};
+    if (!ONLY) {
+        if (__builtin_expect(n_rec == 0u, 0)) return;
+        a_old = alloc_issue_e(bl.alloc_state, n_rec);
+    }
     // distance levels: Le against the element pair's bounds, Lg against the fixed ones; L = 4 Le + Lg
     const uint32_t eix = (pa & 0xF0u) | (pb & 0x0Fu);
     const double t_clash = tb.s_clash[eix], t_cov = tb.s_cov[eix], t_vdw = tb.s_vdw[eix];
@@ -222,31 +260,77 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
         : "=&v"(w1), "=&v"(w2) : "v"(pa), "v"(pb));
     const uint32_t t = tb.lut[(L << 7) | w1 | w2];
     // a probe decides: bit 30 & (either residue carries hydrogens), bit 29 & (residue tables present); bit 31 is never set
-    const lmask m_defer = lm_lt_u32_sv(0x1FFFFFFFu, t & (pa | pb | probe_bits)) & m_valid;
+    lmask m_rare = lm_lt_u32_sv(0x1FFFFFFFu, t & (pa | pb | probe_bits));  // (& m_valid below)
     uint32_t kind = t & 0x1FFFFFFFu;
-    if (ONLY) m_valid &= lm_lt_u32_sv(0u, kind) | m_defer;  // no-interaction candidates are dropped
+    if (ONLY) m_valid &= lm_lt_u32_sv(0u, kind) | m_rare;  // no-interaction candidates are dropped
+    const lmask m_defer = m_rare & m_valid;
     // (f32) of the correctly rounded f64 sqrt (kernels.hip dist_f32), the rare exact path behind a wave-uniform branch
     const double r = (double)__frsqrt_rn((float)s);
     const double y0 = s * r, hr = 0.5 * r;
     double y = __fma_rn(__fma_rn(-y0, y0, s), hr, y0);
-    {
-        const uint32_t low = (uint32_t)__double_as_longlong(y) & 0x1FFFFFFFu;  // the 29 bits a cast to f32 drops
-        // s outside [2^-100, 2^100) (zero, non-finite), or y within 2048 f64 ulps of an f32 rounding boundary
-        const lmask m_exact = m_valid & (lm_lt_u32_sv(0x46300000u - 0x39B00000u - 1u, (uint32_t)__double2hiint(s) - 0x39B00000u) |
-                                         lm_gt_u32_sv(4097u, low - (0x10000000u - 2048u)));
-        if (m_exact) {
-            asm volatile("" ::: "memory");  // keep this a branch (no speculation of the long sequence)
-            if (lm_lane(m_exact, lane)) y = sqrt(s);
-        }
+    const uint32_t low = (uint32_t)__double_as_longlong(y) & 0x1FFFFFFFu;  // the 29 bits a cast to f32 drops
+    // s outside [2^-100, 2^100) (zero, non-finite), or y within 2048 f64 ulps of an f32 rounding boundary
+    const lmask m_exact = m_valid & (lm_lt_u32_sv(0x46300000u - 0x39B00000u - 1u, (uint32_t)__double2hiint(s) - 0x39B00000u) |
+                                     lm_gt_u32_sv(4097u, low - (0x10000000u - 2048u)));
+    if (ONLY) {  // the records that stay are known: ask for their places now, the answer is read after the rare paths
+        n_rec = lm_count(m_valid & ~m_defer);
+        if (n_rec) a_old = alloc_issue_e(bl.alloc_state, n_rec);
     }
     u32x4 rec;
     rec.x = lm_select(m_swap, bzp.w, azp.w); rec.y = lm_select(m_swap, azp.w, bzp.w);
-    rec.z = __float_as_uint((float)y);
-    if (!ONLY) {
-        if (!n_early) return;
-        const Slots sl = alloc_finish<CHUNK>(bl.alloc_state, &result[2], n_early, lane, a_old);
+    uint32_t general;  // (wave-uniform, and opaque to the optimiser in both arms: as a bool it comes back as a lane mask + three scalar instructions per use)
+    if (__builtin_expect((m_exact | m_defer) == 0ull, 1)) {
+        rec.z = __float_as_uint((float)y);
+        rec.w = kind;
+        if (ONLY) { if (n_rec == 0u) return; }
+        // The allocator's common case, hand-scheduled (left to the compiler: ~25 scalar instructions of selects and flag words): the n records
+        // fit the block's current chunk (used + n <= CHUNK) and the chunk lies wholly inside the first 2^32 bytes of the caller's buffer (chunk <
+        // cap_chunks) -> one run, scalar base + the 32-bit byte offset (position + rank) * 16, stored under the valid mask as exec.
         const uint32_t rank = lm_rank(m_valid);
-        if (m_defer) {  // rare: the probe pass patches these kinds in place
+        uint32_t t0, t1, off;
+        lmask save;
+        asm volatile(
+            "v_readfirstlane_b32 %[t0], %[olo]\n\t"
+            "v_readfirstlane_b32 %[t1], %[ohi]\n\t"
+            "s_add_u32 %[g], %[t0], %[n]\n\t"
+            "s_cmp_le_u32 %[g], %[chunk]\n\t"
+            "s_cselect_b32 %[g], %[t1], -1\n\t"
+            "s_cmp_lt_u32 %[g], %[cap]\n\t"
+            "s_cselect_b32 %[g], 0, 1\n\t"
+            "s_cbranch_scc0 9f\n\t"
+            "s_lshl_b32 %[t1], %[t1], %[shift]\n\t"
+            "s_add_u32 %[t1], %[t1], %[t0]\n\t"
+            "v_add_lshl_u32 %[off], %[rank], %[t1], 4\n\t"
+            "s_and_saveexec_b64 %[save], %[mv]\n\t"
+            "global_store_dwordx4 %[off], %[rec], %[base] nt\n\t"
+            "s_mov_b64 exec, %[save]\n\t"
+            "9:"
+            : [g] "=&s"(general), [t0] "=&s"(t0), [t1] "=&s"(t1), [off] "=&v"(off), [save] "=&s"(save)
+            : [olo] "v"(a_old.x), [ohi] "v"(a_old.y), [n] "s"(n_rec), [chunk] "s"(CHUNK), [cap] "s"(cap_chunks), [shift] "n"(chunk_shift_of(CHUNK)), [rank] "v"(rank),
+              [mv] "s"(m_valid), [rec] "v"(rec), [base] "s"(tg.out)
+            : "scc", "memory");
+    } else {
+        asm volatile("" ::: "memory");  // keep this a branch (no speculation of the long sequence)
+        if (m_exact) { if (lm_lane(m_exact, lane)) y = sqrt(s); }
+        rec.z = __float_as_uint((float)y);
+        asm volatile("s_mov_b32 %0, 1" : "=s"(general));
+    }
+    if (__builtin_expect(general != 0u, 0)) {  // ---- chunk crossing / refill / scratch / a probe decides: the general placement ----
+        if (ONLY) {
+            if (m_defer) {  // candidates whose rules need a probe go to the deferred pass (k_pairs_deferred), as global slot pairs
+                const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], (uint32_t)__popcll(m_defer), lane);
+                if (lm_lane(m_defer, lane)) {
+                    const uint32_t dr = lm_rank(m_defer);
+                    const unsigned long long p = dr < ds.n0 ? ds.pos0 + dr : ds.pos1 + (dr - ds.n0);
+                    if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(slot0 + hl, nb); else atomicOr(&result[1], 8ull);
+                }
+                m_valid &= ~m_defer;
+            }
+            if (n_rec == 0u) return;
+        }
+        const Slots sl = alloc_finish<CHUNK>(bl.alloc_state, &result[2], n_rec, lane, u64_of(a_old));
+        const uint32_t rank = lm_rank(m_valid);
+        if (!ONLY && m_defer) {  // the probe pass patches these kinds in place: it is told the records' final positions
             const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], 2u * (uint32_t)__popcll(m_defer), lane);  // (even counts: a pair never straddles a chunk)
             if (lm_lane(m_defer, lane)) {
                 const unsigned long long pos = rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0);
@@ -258,34 +342,7 @@ DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, Block
             }
         }
         rec.w = kind;
-        if (sl.n0 == n_early && sl.pos0 + n_early <= tg.capacity) {  // one run inside the caller's buffer
-            lm_store_records(m_valid, reinterpret_cast<uint4 *>(tg.out) + sl.pos0, rank << 4, rec);
-        } else if (lm_lane(m_valid, lane)) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
-            uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
-            if (d) store_record(d, make_uint4(rec.x, rec.y, rec.z, rec.w));
-        }
-        return;
-    }
-    rec.w = kind;
-    if (m_defer) {  // candidates whose rules need a probe go to the deferred pass (k_pairs_deferred), as global slot pairs
-        const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], (uint32_t)__popcll(m_defer), lane);
-        if (lm_lane(m_defer, lane)) {
-            const uint32_t dr = lm_rank(m_defer);
-            const unsigned long long p = dr < ds.n0 ? ds.pos0 + dr : ds.pos1 + (dr - ds.n0);
-            if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(slot0 + hl, nb); else atomicOr(&result[1], 8ull);
-        }
-        m_valid &= ~m_defer;
-    }
-    const uint32_t n = (uint32_t)__popcll(m_valid);
-    if (n) {  // compacted, coalesced store of the batch's records straight from registers
-        const Slots sl = alloc_chunked<CHUNK>(bl.alloc_state, &result[2], n, lane);
-        const uint32_t rank = lm_rank(m_valid);
-        if (sl.n0 == n && sl.pos0 + n <= tg.capacity) {  // one run inside the caller's buffer
-            lm_store_records(m_valid, reinterpret_cast<uint4 *>(tg.out) + sl.pos0, rank << 4, rec);
-        } else if (lm_lane(m_valid, lane)) {  // the run crosses a chunk end or the end of the caller's buffer (scratch until k_fixup)
-            uint4 *d = emit_slot(tg, rank < sl.n0 ? sl.pos0 + rank : sl.pos1 + (rank - sl.n0), result);
-            if (d) store_record(d, make_uint4(rec.x, rec.y, rec.z, rec.w));
-        }
+        store_batch_general(sl, m_valid, n_rec, rank, rec, tg, result, lane);
     }
 }
 
@@ -316,6 +373,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
     const uint32_t probe_bits = in.n_res != 0u ? (1u << 29) : 0u;  // residue tables present: CYS SG pairs in the covalent band get their dihedral probe
     const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar};
     const double r2m = gp->r2m;
+    // chunks that lie wholly inside the caller's buffer: a batch placed in one of them needs no further capacity test (alloc_take_e)
+    // (and inside its first 2^32 bytes: the fast path addresses with a 32-bit byte offset; what lies beyond takes the general path)
+    const uint32_t cap_chunks = (uint32_t)min(tg.capacity >> chunk_shift_of(kChunkE), (unsigned long long)((1u << 28) / kChunkE));
     WaveLdsE &w = wl[wave];
     // task distribution as in k_pairs: block group (b mod 8) = one XCD = one contiguous eighth of the tasks, static first task per wave
     const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
@@ -392,19 +452,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                 bool more = kSubs == 1u || __any(it0 < len);
 #pragma unroll 1
                 while (more) {
-                    // Phase 1, one run: up to kEAcc prefilter tests per lane in groups of kEGroup, results pushed into the lane's mask word
-                    // (test q of the run ends up in bit nacc - 1 - q).  Lanes whose window is exhausted read records 0..7 of the chunk
-                    // (any staged data will do: their bits are dropped below).
+                    // Phase 1, one run: up to kEAcc prefilter tests per lane in groups of kEGroup, results pushed into the lane's mask word.
+                    // Every lane reads from its own window start onwards, ALL addresses of the run being immediate offsets from one base: a
+                    // lane whose window is exhausted reads on past it (other records, the wave's other arrays, at worst beyond the block's LDS,
+                    // which reads as zero) and its bits are dropped below -- no per-group clamp, select or address arithmetic.
                     const uint32_t acc0 = it0;
                     uint32_t mask = 0, nacc = 0;
-#pragma unroll 1
-                    do {
-                        const float4 *win = w.nrec + (it0 < len ? off + it0 : 0u);
+                    const float4 *win = w.nrec + (off + it0);
+#pragma unroll
+                    for (uint32_t g = 0; g < kEAcc / kEGroup; ++g) {
 #pragma unroll
                         for (uint32_t u0 = 0; u0 < kEGroup; u0 += kReadAhead) {
                             float rx[kReadAhead], ry[kReadAhead], rz[kReadAhead], rw[kReadAhead];
 #pragma unroll
-                            for (uint32_t u = 0; u < kReadAhead; ++u) { const float4 r = win[u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; rw[u] = r.w; }
+                            for (uint32_t u = 0; u < kReadAhead; ++u) { const float4 r = win[g * kEGroup + u0 + u]; rx[u] = r.x; ry[u] = r.y; rz[u] = r.z; rw[u] = r.w; }
                             // |n|^2 - 2 n.h against thr = r2m - |h|^2; the FMAs link-major over the tests in flight so that neighbours are independent
                             float acc[kReadAhead];
 #pragma unroll
@@ -416,27 +477,31 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
 #pragma unroll
                             for (uint32_t u = 0; u < kReadAhead; ++u) push_pass(mask, acc[u], thr);
                         }
-                        it0 += kEGroup; nacc += kEGroup;
-                        more = __any(it0 < len);
-                    } while (more && nacc < kEAcc);
-                    // tests of this run past the lane's window end looked at other atoms: drop them
-                    const uint32_t rem = len > acc0 ? len - acc0 : 0u;
-                    if (rem < nacc) mask = rem ? mask & (0xFFFFFFFFu << (nacc - rem)) : 0u;
-                    // (bit 31 - lz <-> test q = lz - (32 - nacc) <-> neighbour slot cs + off + acc0 + q)
-                    const uint32_t tag = lane_tag + (cs + off + acc0 - (32u - nacc));
-                    for (;;) {
+                        nacc = (g + 1u) * kEGroup;
+                        more = __any(it0 + nacc < len);
+                        if (!more) break;
+                    }
+                    it0 += nacc;
+                    // left-align (test q of the run -> bit 31 - q) and drop the tests past the lane's window end: keep the top min(rem, 32) bits
+                    // = the low word of 0xFFFFFFFF00000000 >> rem
+                    const uint32_t rem = min(len > acc0 ? len - acc0 : 0u, 32u);
+                    mask = (mask << (32u - nacc)) & (uint32_t)(0xFFFFFFFF00000000ull >> rem);
+                    const uint32_t tag = lane_tag + (cs + off + acc0);  // (bit 31 - lz <-> test q = lz <-> neighbour slot cs + off + acc0 + q)
+                    {
                         uint32_t qb = __builtin_amdgcn_readfirstlane(qbyte);  // (wave-uniform by construction: say so)
                         compact_rounds_e(mask, tag, qb, queue_lds + 256u);
+                        while (qb >= queue_lds + 256u) {  // a full batch: the 64 entries at the tail; then the rest of the run's survivors
+                            qb -= 256u;
+                            exact_batch_e<true, ONLY, kChunkE>(K, tb, w, bl, so, qb - queue_lds, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);
+                            compact_rounds_e(mask, tag, qb, queue_lds + 256u);
+                        }
                         qbyte = qb;
-                        if (qbyte < queue_lds + 256u) break;  // every test of the run is in the queue
-                        qbyte -= 256u;                        // a full batch: the 64 entries at the tail
-                        exact_batch_e<true, ONLY, kChunkE>(K, tb, w, bl, so, (qbyte - queue_lds) >> 2, 64u, slot0, tg, result, lane, wflags, probe_bits);
                     }
                     if (kSubs > 1u) { it0 += (kSubs - 1u) * kEAcc; more = __any(it0 < len); }
                 }
             }
         }
-        if (qbyte != queue_lds) exact_batch_e<false, ONLY, kChunkE>(K, tb, w, bl, so, 0u, (qbyte - queue_lds) >> 2, slot0, tg, result, lane, wflags, probe_bits);  // the home records go with the task: drain
+        if (qbyte != queue_lds) exact_batch_e<false, ONLY, kChunkE>(K, tb, w, bl, so, 0u, (qbyte - queue_lds) >> 2, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);  // the home records go with the task: drain
         uint32_t nxt_task = 0;
         if (lane == 0) nxt_task = atomicAdd(ctr, 1u);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);
