@@ -14,7 +14,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libarpeggia_amd.so"
 SOURCES = ["kernels.hip", "engine.cpp", "structure.cpp", "table.cpp", "table_dev.hip"]
-HEADERS = ["arp_internal.h", "host_common.h", "grid.inl", "pairs.inl", "pairs_emit.inl", "batch.inl", "sap.inl", "table_dev.h", "table_host.inl",
+HEADERS = ["arp_internal.h", "host_common.h", "grid.inl", "pairs.inl", "pairs_emit.inl", "batch.inl", "sap.inl", "table_dev.h", "../../tests/hosttable/table_host.inl",
            "../../include/arpeggia_amd.h"]
 STAMP = PKG / "build" / "libarpeggia_amd.sha256"  # hash of every source + the flags the library was last built from
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-result",
@@ -80,7 +80,7 @@ HOST_TABLE_LIB = PKG.parent / "tests" / "hosttable" / "build" / "libarpeggia_amd
 
 def build_host_table_library(force: bool = False) -> Path:
     """TEST-ONLY library: the product's objects with table.cpp recompiled under -DARP_WITH_HOST_TABLE, i.e. plus the round-1 host assembly
-    of the contact table (csrc/table_host.inl) that tests/test_gpu_parity.py cross-checks the device table with.  The product library
+    of the contact table (tests/hosttable/table_host.inl) that tests/test_gpu_parity.py cross-checks the device table with.  The product library
     does not contain that code."""
     build_library()  # the product's objects must be current
     stamp = HOST_TABLE_LIB.with_suffix(".sha256")

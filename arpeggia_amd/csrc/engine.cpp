@@ -80,6 +80,12 @@ void make_dev_params(const arp_params &p, DevParams *d) {
             d->s_clash[a * 16 + b] = bound_lt(sum_cov - c);
             d->s_cov[a * 16 + b] = bound_lt(sum_cov + c);
             d->s_vdw[a * 16 + b] = bound_lt(sum_vdw + c);
+            // vdw.rs:32-43 is a first-match chain (clash, covalent, vdW); k_emit counts how many of the three bounds a distance is below,
+            // which is the same thing only for NESTED bounds.  A negative vdw_comp (cov - c > cov + c) or caller radii with vdw < cov break the
+            // nesting; raising each bound to its predecessor restores it without changing any first-match outcome: below the clash bound
+            // the pair is a clash whatever the others say, and a distance at or above it is below max(cov, clash) exactly when it is below cov.
+            d->s_cov[a * 16 + b] = std::max(d->s_cov[a * 16 + b], d->s_clash[a * 16 + b]);
+            d->s_vdw[a * 16 + b] = std::max(d->s_vdw[a * 16 + b], d->s_cov[a * 16 + b]);
         }
         d->s_hacc[a] = bound_le(p.h_vdw_radius + p.vdw_radius[a] + c);  // hbond.rs:54
     }
@@ -721,11 +727,20 @@ template <class F>
 void run_helpers(int helpers, size_t n, F &&fn) {  // fn(item) over [0, n) on up to `helpers` threads (dynamic: items differ in size)
     if (helpers <= 1 || n <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
     std::atomic<size_t> next{0};
-    auto work = [&]() { for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(k); };
+    std::exception_ptr first_error;  // (as parallel_for, host_common.h: no exception leaves a helper thread, none unwinds past a joinable one)
+    std::mutex error_mu;
+    auto work = [&]() noexcept {
+        try { for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(k); }
+        catch (...) { next.store(n, std::memory_order_relaxed); std::lock_guard<std::mutex> lk(error_mu); if (!first_error) first_error = std::current_exception(); }
+    };
     std::vector<std::thread> th;
-    for (int t = 1; t < helpers; t++) try { th.emplace_back(work); } catch (const std::system_error &) { break; }
-    work();
-    for (auto &t : th) t.join();
+    th.reserve((size_t)helpers);
+    {
+        struct JoinAll { std::vector<std::thread> &t; ~JoinAll() { for (auto &x : t) if (x.joinable()) x.join(); } } join_all{th};
+        for (int t = 1; t < helpers; t++) try { th.emplace_back(work); } catch (const std::system_error &) { break; }
+        work();
+    }
+    if (first_error) std::rethrow_exception(first_error);
 }
 
 const bool g_batch_timing = getenv("ARP_TIMING") != nullptr;
@@ -957,7 +972,7 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
     const int helpers = std::max(1, std::min(8, hw / std::max(1, n_ctx)));
     std::vector<arp_status> st(n_ctx, ARP_OK);
     std::vector<std::string> msg(n_ctx);
-    auto device_worker = [&](int d) {
+    auto device_worker_body = [&](int d) {
         auto fail = [&](arp_status s) { st[d] = s; msg[d] = arp_last_error(); };
         // plan: consecutive members of the device's share form packs; what cannot be packed runs alone
         std::vector<PackPlan> plans;
@@ -1006,7 +1021,21 @@ extern "C" arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_
             for (int q = 0; q < 2; q++) if (slot[q].ctx) (void)hipStreamSynchronize(slot[q].ctx->stream);
         }
     };
+    // ARP_ABI_CATCH only guards the calling thread: an exception that left a std::thread's function would terminate the host process.  Every
+    // worker therefore turns its own exceptions into a status (msg[d] is a short constant: no allocation on the way out of bad_alloc).
+    auto device_worker = [&](int d) noexcept {
+        try { device_worker_body(d); }
+        catch (const std::bad_alloc &) { st[d] = ARP_ERR_OOM; try { msg[d] = "out of host memory in a batch worker"; } catch (...) {} }
+        catch (const std::exception &e) { st[d] = ARP_ERR_HIP; try { msg[d] = e.what(); } catch (...) {} }
+        catch (...) { st[d] = ARP_ERR_HIP; }
+        if (st[d] != ARP_OK) {  // whatever was launched on this device's streams must not outlive the buffers the caller is about to get back
+            (void)hipStreamSynchronize(ctxs[d]->stream);
+            if (ctxs[d]->peer) (void)hipStreamSynchronize(ctxs[d]->peer->stream);
+        }
+    };
     std::vector<std::thread> th;
+    th.reserve((size_t)n_ctx);  // (no reallocation while joinable threads sit in the vector)
+    struct JoinAll { std::vector<std::thread> &t; ~JoinAll() { for (auto &x : t) if (x.joinable()) x.join(); } } join_all{th};
     for (int d = 1; d < n_ctx; d++)
         try { th.emplace_back(device_worker, d); } catch (const std::system_error &) { device_worker(d); }  // no thread: this device's share runs here
     device_worker(0);

@@ -111,14 +111,26 @@ void parallel_for(size_t n, size_t min_per_worker, F &&fn) {
     size_t workers = (size_t)host_threads();
     if (min_per_worker && n / min_per_worker < workers) workers = n / min_per_worker;
     if (workers <= 1) { fn((size_t)0, n, (size_t)0); return; }
+    // An exception must not leave a std::thread's function (std::terminate) nor unwind past joinable threads: a worker parks its exception,
+    // the guard joins on every path, and the caller rethrows the first one -- it then reaches the C ABI's catch like any exception of the
+    // calling thread.
     std::vector<std::thread> th;
     th.reserve(workers);
-    size_t started = 0;  // slices [0, started) run on threads of their own; the caller takes the last one and any that could not get a thread
-    for (; started + 1 < workers; started++) {
-        const size_t w = started;
-        try { th.emplace_back([&, w]() { fn(n * w / workers, n * (w + 1) / workers, w); }); } catch (const std::system_error &) { break; }
+    std::exception_ptr first_error;
+    std::mutex error_mu;
+    auto guarded = [&](size_t w) noexcept {
+        try { fn(n * w / workers, n * (w + 1) / workers, w); }
+        catch (...) { std::lock_guard<std::mutex> lk(error_mu); if (!first_error) first_error = std::current_exception(); }
+    };
+    {
+        struct JoinAll { std::vector<std::thread> &t; ~JoinAll() { for (auto &x : t) if (x.joinable()) x.join(); } } join_all{th};
+        size_t started = 0;  // slices [0, started) run on threads of their own; the caller takes the last one and any that could not get a thread
+        for (; started + 1 < workers; started++) {
+            const size_t w = started;
+            try { th.emplace_back([&guarded, w]() { guarded(w); }); } catch (const std::system_error &) { break; }
+        }
+        for (size_t w = started; w < workers; w++) guarded(w);
     }
-    for (size_t w = started; w < workers; w++) fn(n * w / workers, n * (w + 1) / workers, w);
-    for (auto &t : th) t.join();
+    if (first_error) std::rethrow_exception(first_error);
 }
 }  // namespace arp

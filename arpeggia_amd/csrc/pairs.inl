@@ -32,6 +32,7 @@ constexpr uint32_t kPairBlocks = 256 * 8;   // ordered modes: blocks, each ownin
 constexpr int kEmitWavesPerSimd = 6;       // register budget of the emit kernel: 80 VGPRs at 6, 64 at 8
 constexpr uint32_t kEmitBlocks = (1024u * kEmitWavesPerSimd) / kWavesPerBlock;  // emit mode: blocks of 8 waves, 6 waves per SIMD
 constexpr uint32_t kGrab = 1;              // wave-tasks drawn per atomic
+constexpr uint32_t kESlotBits = 24;        // k_emit (pairs_emit.inl): neighbour slot bits of a queue entry (v_mul_u32_u24 turns the entry into the record offset); launch_emit routes larger inputs to k_pairs
 // records per global allocation (one device atomic each).  The wave whose allocation crosses the end of the block's chunk fetches the
 // next one while the block's other waves sleep: 2048 -> 4096 halves those stalls (emit 221 -> 208 us); 8192 gains 2 us more and costs
 // the fix-up 8 us (holes grow with the chunk).
@@ -671,7 +672,7 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
         hipLaunchKernelGGL(k_gather, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.perm,
                            (const uint32_t *)ws.slot_cell, ws.sorted);
     } else {
-        hipLaunchKernelGGL(k_place, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.cell_of_atom,
+        hipLaunchKernelGGL(k_place, dim3((n + 256u * kPlacePer - 1u) / (256u * kPlacePer) + (n ? 0u : 1u)), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.cell_of_atom,
                            (const uint32_t *)ws.rank_of_atom, ws.sorted);
     }
     P1();
@@ -742,16 +743,11 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
         return;
     }
     // The default is k_emit (pairs_emit.inl).  This file's k_pairs<kEmit> -- both exact operands gathered, 8-byte queue entries -- is the
-    // one alternative kept: it takes the inputs beyond k_emit's 2^26 slots, and ARP_EMIT_KERNEL=gather selects it for the parity suite.
+    // one alternative kept: it takes the inputs beyond k_emit's 2^24 slots, and ARP_EMIT_KERNEL=gather selects it for the parity suite.
     static const bool gather = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'g'; }();
-    if (!gather && in.n < (1u << 26) - 64u) { launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred); return; }
+    if (!gather && in.n < (1u << kESlotBits) - 64u) { launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred); return; }
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
-    static const uint32_t emit_blocks = [] {  // tuning knob for experiments: ARP_EMIT_BLOCKS (<= 1600)
-        const char *e = getenv("ARP_EMIT_BLOCKS");
-        const long v = e ? atol(e) : 0;
-        return (v >= 8 && v <= 1600) ? (uint32_t)v : kEmitBlocks;
-    }();
-    const uint32_t nb = blocks_for(in.n, emit_blocks);
+    const uint32_t nb = blocks_for(in.n, kEmitBlocks);
     if (prof) prof->begin("pairs_emit", st);
     hipLaunchKernelGGL((k_pairs<kEmit, false>), dim3(nb), dim3(kWavesPerBlock * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params,
                        (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,

@@ -23,7 +23,6 @@ constexpr uint32_t kEChunk = 128;             // staged neighbour records per ch
 constexpr int kEWaves = 12;                   // waves per block: two blocks per CU share the CU's LDS, 6 waves per SIMD
 constexpr uint32_t kEBlocks = 256u * 2u;
 constexpr int kEWavesPerSimd = (kEWaves * 2) / 4;
-constexpr uint32_t kESlotBits = 26;           // neighbour slot bits of a queue entry; the launcher routes larger inputs to k_pairs
 constexpr uint32_t kESlotMask = (1u << kESlotBits) - 1u;
 constexpr uint32_t kEGroup = 8;               // prefilter tests per lane between two "is any window still open" checks
 constexpr uint32_t kEAcc = 32;                // prefilter tests per lane between two compactions (one mask word)
@@ -185,22 +184,37 @@ DEVFN void store_batch_general(const Slots &sl, lmask m_valid, uint32_t n_rec, u
 // k_patch_deferred (pairs.inl).
 // Round 4 (scalar diet): one rare-path branch for "a probe decides" and "the square root needs the exact routine" together, the
 // allocator's common case in ~10 scalar instructions (alloc_take_e), masks straight out of the compares.
-template <bool FULL, bool ONLY, uint32_t CHUNK>
-DEVFN void exact_batch_e(const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, const Sorted &so, uint32_t qoff, uint32_t count, uint32_t slot0,
-                         const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
+// Round 4: the batch in two halves.  exact_issue_e reads the batch's queue entries and sends the neighbour gathers on their way; the caller
+// then runs the compaction rounds of the run's remaining survivors (which may overwrite the queue entries: they are in registers) and only
+// then exact_finish_e, so the L2 / HBM round trip of the gathers -- the longest single wait of a batch -- overlaps those rounds instead of
+// parking the wave (counters after the scalar diet: 54 % of wave-cycles at s_waitcnt).
+struct ExactRegs { uint32_t e; u32x4 bxy, bzp; unsigned long long kb; };
+template <bool FULL>
+DEVFN ExactRegs exact_issue_e(const WaveLdsE &w, const Sorted &so, uint32_t qoff, uint32_t count, uint32_t lane) {
     qoff = __builtin_amdgcn_readfirstlane(qoff); count = __builtin_amdgcn_readfirstlane(count);  // (wave-uniform by construction: say so)
     wave_lds_fence();  // lanes read entries other lanes wrote
-    uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(w.queue) + qoff + 4u * lane);
-    if (!FULL) e = lane < count ? e : 0u;
+    ExactRegs g;
+    g.e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(w.queue) + qoff + 4u * lane);
+    if (!FULL) g.e = lane < count ? g.e : 0u;
     wave_lds_fence();
-    const uint32_t hl = e >> kESlotBits, nb = e & kESlotMask;
-    uint32_t goff;  // 48 nb as two full-rate instructions (fat_at, pairs.inl)
-    asm("v_lshl_add_u32 %0, %1, 1, %1\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(goff) : "v"(nb));
+    uint32_t goff;  // 48 * (the entry's low 24 bits = the neighbour slot) in one instruction: the 24-bit multiply ignores the home-lane byte
+    asm("v_mul_u32_u24 %0, %1, 48" : "=v"(goff) : "v"(g.e));
     const char *gp = reinterpret_cast<const char *>(so.fat) + (size_t)goff;
-    const u32x4 bxy = *reinterpret_cast<const u32x4 *>(gp), bzp = *reinterpret_cast<const u32x4 *>(gp + 16);
-    const unsigned long long kb = *reinterpret_cast<const unsigned long long *>(gp + 32);
-    const u32x4 axy = w.hxy[hl], azp = w.hzp[hl];
-    const unsigned long long ka = w.hkey[hl];
+    g.bxy = *reinterpret_cast<const u32x4 *>(gp); g.bzp = *reinterpret_cast<const u32x4 *>(gp + 16);
+    g.kb = *reinterpret_cast<const unsigned long long *>(gp + 32);
+    return g;
+}
+template <bool FULL, bool ONLY, uint32_t CHUNK>
+DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, uint32_t count, uint32_t slot0,
+                          const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
+    count = __builtin_amdgcn_readfirstlane(count);
+    const uint32_t e = g.e, hl = e >> kESlotBits, nb = e & kESlotMask;
+    const u32x4 bxy = g.bxy, bzp = g.bzp;
+    const unsigned long long kb = g.kb;
+    // (two addresses, hl * 16 and hl * 8 from the wave's base, the arrays as immediate offsets)
+    const char *wb = reinterpret_cast<const char *>(&w);
+    const u32x4 axy = *reinterpret_cast<const u32x4 *>(wb + offsetof(WaveLdsE, hxy) + 16u * hl), azp = *reinterpret_cast<const u32x4 *>(wb + offsetof(WaveLdsE, hzp) + 16u * hl);
+    const unsigned long long ka = *reinterpret_cast<const unsigned long long *>(wb + offsetof(WaveLdsE, hkey) + 8u * hl);
     // pdbtbx Atom::distance before the sqrt, f64, the reference's operation order, no contraction
     const double s = sq_dist(words_f64(axy.x, axy.y), words_f64(axy.z, axy.w), words_f64(azp.x, azp.y), words_f64(bxy.x, bxy.y), words_f64(bxy.z, bxy.w),
                              words_f64(bzp.x, bzp.y));
@@ -492,8 +506,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                         compact_rounds_e(mask, tag, qb, queue_lds + 256u);
                         while (qb >= queue_lds + 256u) {  // a full batch: the 64 entries at the tail; then the rest of the run's survivors
                             qb -= 256u;
-                            exact_batch_e<true, ONLY, kChunkE>(K, tb, w, bl, so, qb - queue_lds, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);
-                            compact_rounds_e(mask, tag, qb, queue_lds + 256u);
+                            const ExactRegs g = exact_issue_e<true>(w, so, qb - queue_lds, 64u, lane);
+                            compact_rounds_e(mask, tag, qb, queue_lds + 256u);  // (while the gathers are in flight)
+                            exact_finish_e<true, ONLY, kChunkE>(g, K, tb, w, bl, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);
                         }
                         qbyte = qb;
                     }
@@ -501,7 +516,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                 }
             }
         }
-        if (qbyte != queue_lds) exact_batch_e<false, ONLY, kChunkE>(K, tb, w, bl, so, 0u, (qbyte - queue_lds) >> 2, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);  // the home records go with the task: drain
+        if (qbyte != queue_lds) {  // the home records go with the task: drain
+            const uint32_t left = (qbyte - queue_lds) >> 2;
+            const ExactRegs g = exact_issue_e<false>(w, so, 0u, left, lane);
+            exact_finish_e<false, ONLY, kChunkE>(g, K, tb, w, bl, left, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);
+        }
         uint32_t nxt_task = 0;
         if (lane == 0) nxt_task = atomicAdd(ctr, 1u);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);

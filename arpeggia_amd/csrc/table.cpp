@@ -24,7 +24,7 @@
 
 namespace arp {
 
-#ifdef ARP_WITH_HOST_TABLE   // host-side plane maths: only the test-only host assembly (table_host.inl) fits planes on the CPU
+#ifdef ARP_WITH_HOST_TABLE   // host-side plane maths: only the test-only host assembly (tests/hosttable/table_host.inl) fits planes on the CPU
 // ---- plane maths (residues.rs:24-75, 270-298) ----------------------------------------------------------------------
 // Least-squares plane: centroid + eigenvector of the smallest eigenvalue of the 3x3 scatter matrix (cyclic Jacobi).
 // nalgebra's svd.u.column(2) is the same direction up to sign; every use folds the angle into [0, 90] degrees.
@@ -320,12 +320,17 @@ struct TableCache {
     std::vector<uint32_t> ring_model_rank;
     std::shared_ptr<EntityBook> book;
     std::thread book_job;                     // fills `book` while the first call's device work runs; joined before a table gets the book
-    void wait_for_book() { if (book_job.joinable()) book_job.join(); }
+    std::exception_ptr book_error;            // what the job threw, if anything: rethrown on the calling thread by wait_for_book
+    void wait_for_book() {
+        if (book_job.joinable()) book_job.join();
+        if (book_error) { std::exception_ptr e = book_error; book_error = nullptr; std::rethrow_exception(e); }
+    }
+    void join_book() noexcept { if (book_job.joinable()) book_job.join(); }
     std::mutex mu;                            // held for the whole of a device-table call on this structure
     std::string rings_groups; bool have_rings_dev = false;   // the ring entities as the device wants them, for this chain-group spec
     std::vector<RingEnt> rings_dev;
     DevStructure dev;
-    ~TableCache() { wait_for_book(); if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); } }
+    ~TableCache() { join_book(); if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); } }
 };
 void free_table_cache(void *p) { delete (TableCache *)p; }
 uint32_t be32(const char *p) { return ((uint32_t)(unsigned char)p[0] << 24) | ((uint32_t)(unsigned char)p[1] << 16) | ((uint32_t)(unsigned char)p[2] << 8) | (uint32_t)(unsigned char)p[3]; }
@@ -335,7 +340,8 @@ uint32_t be32s(const std::string &v) { char b[4] = {0, 0, 0, 0}; memcpy(b, v.dat
 TableCache *table_cache_of(arp_structure *s) {
     std::lock_guard<std::mutex> guard(s->table_cache_mu);
     if (s->table_cache) return (TableCache *)s->table_cache;
-    TableCache *c = new TableCache();
+    std::unique_ptr<TableCache> holder(new TableCache());  // (published at the end: an exception on the way leaks nothing, and its job is joined)
+    TableCache *c = holder.get();
     const size_t n = s->n, nr = s->residues.size();
     const bool timing = getenv("ARP_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -447,10 +453,13 @@ TableCache *table_cache_of(arp_structure *s) {
                 bk->lens[n_atoms + k] = lens_of(e);
             }
         };
-        try { c->book_job = std::thread(fill); } catch (const std::system_error &) { fill(); }  // (no thread to be had: filled here)
+        // (an exception must not leave the thread's function: it is parked and rethrown by wait_for_book on the thread that asks for the book)
+        TableCache *cw = c;
+        auto job = [fill, cw]() noexcept { try { fill(); } catch (...) { cw->book_error = std::current_exception(); } };
+        try { c->book_job = std::thread(job); } catch (const std::system_error &) { fill(); }  // (no thread to be had: filled here)
     }
     lap("entity book (job started)");
-    s->table_cache = c; s->table_cache_free = free_table_cache;
+    s->table_cache = holder.release(); s->table_cache_free = free_table_cache;
     return c;
 }
 
@@ -628,7 +637,7 @@ arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *g
 }  // namespace
 
 #ifdef ARP_WITH_HOST_TABLE
-#include "table_host.inl"
+#include "../../tests/hosttable/table_host.inl"  // test-only: not part of the product library (build.py: build_host_table_library)
 #endif
 
 extern "C" arp_status arp_get_contacts(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp, double dist_cutoff,

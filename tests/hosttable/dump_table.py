@@ -1,4 +1,4 @@
-"""Contact tables from the HOST assembly (csrc/table_host.inl), which only the test-only library contains.  Run by
+"""Contact tables from the HOST assembly (tests/hosttable/table_host.inl), which only the test-only library contains.  Run by
 tests/test_gpu_parity.py::test_device_table_equals_the_host_assembly in a process of its own:
     ARPEGGIA_AMD_LIB=tests/hosttable/build/libarpeggia_amd_hosttable.so ARP_TABLE_HOST=1 python tests/hosttable/dump_table.py
 Prints one JSON object {case: {groups: [csv lines]}}."""

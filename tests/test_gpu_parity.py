@@ -105,6 +105,45 @@ def test_stress_structures_cover_every_atomic_rule(ctx, kw, groups):
             assert seen & (1 << ob.INTERACTIONS.index(name)), f"stress input never produced {name}"
 
 
+@pytest.mark.parametrize("vdw_comp", [-0.1, -0.6])
+def test_negative_vdw_comp_keeps_the_first_match_order(ctx, vdw_comp):
+    """vdw.rs:32-43 with a negative compensation: cov - c > cov + c, so the three bounds are not nested; a distance between them is a
+    StericClash (first match), never a CovalentBond.  Every emitter against the oracle."""
+    rec = synth.gen_stress(n_res=400, seed=7)
+    prod = aa.Structure.from_records(rec)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+    got, want = run_both(ctx, prod, orc, "/", vdw_comp, 6.5)
+    assert_pairs_equal(got, want, f"c={vdw_comp}")
+    only = ctx.atomic_contacts(prod.view("/"), aa.default_params(vdw_comp, 6.5, contacts_only=True))
+    assert_pairs_equal(only, want[want["kind"] != 0], f"contacts only, c={vdw_comp}")
+    assert (want["kind"] & (1 << ob.INTERACTIONS.index("StericClash"))).any()
+
+
+def test_radii_with_vdw_below_cov_agree_between_the_emitters(ctx):
+    """Caller radii whose van-der-Waals sum lies below the covalent sum (the API accepts them; the oracle has no radius knob): the
+    single-pass emitter (distance levels counted, k_emit), the ordered one (first-match booleans, classify_fast) and the probe variant
+    (contacts-only ordered fill, classify<true>) must agree record for record."""
+    rec = synth.gen_stress(n_res=300, seed=12)
+    prod = aa.Structure.from_records(rec)
+    view = prod.view("/")
+    base = aa.default_params(0.1, 6.5)
+    for k in range(16):
+        base.vdw_radius[k] = 0.4 + 0.05 * k   # far below the covalent radii of the classes that occur
+    def with_flags(**kw):
+        p = aa.default_params(0.1, 6.5, **kw)
+        for k in range(16):
+            p.vdw_radius[k] = base.vdw_radius[k]
+        return p
+    emit = canon(ctx.atomic_contacts(view, with_flags()))
+    ordered = canon(ctx.atomic_contacts(view, with_flags(deterministic=True)))
+    probes = canon(ctx.atomic_contacts(view, with_flags(deterministic=True, contacts_only=True)))
+    assert len(emit) == len(ordered) and np.array_equal(emit["i"], ordered["i"]) and np.array_equal(emit["j"], ordered["j"])
+    assert np.array_equal(emit["kind"], ordered["kind"])
+    kept = emit[emit["kind"] != 0]
+    assert len(kept) == len(probes) and np.array_equal(kept["kind"], probes["kind"])
+    assert not (emit["kind"] & (1 << ob.INTERACTIONS.index("VanDerWaalsContact"))).any()  # the vdW band is empty: it lies inside the covalent one
+
+
 def test_cys_without_cb_is_an_error_like_the_reference_panic(ctx):
     # vdw.rs:55-58: cb1 = residue.atoms().find(CB).unwrap()
     rec = synth.gen_stress(n_res=60, seed=21, hydrogens=False)
