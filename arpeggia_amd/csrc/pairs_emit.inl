@@ -109,6 +109,14 @@ DEVFN void compact_rounds_e(uint32_t &mask, uint32_t tag, uint32_t &qbyte, uint3
         : "vcc", "scc", "memory");
 }
 
+// mask = 2 * mask + (d2 < thr), as the sign bit of d2 - thr shifted in: a full-rate subtract and one v_alignbit_b32 instead of the half-rate
+// v_cmp_le_f32 + v_addc_co_u32 pair of push_pass (pairs.inl) -- 8.2 -> ~4.6 cycles of the SIMD's vector issue per test
+// (tests/microbench/issue_mix.hip: "cmp+addc" against "sub+alignbit").  A NaN may pass: the exact phase drops it.
+DEVFN void push_sign_e(uint32_t &mask, float d2, float thr) {
+    float t;
+    asm("v_sub_f32 %1, %2, %3\n\tv_alignbit_b32 %0, %0, %1, 31" : "+v"(mask), "=&v"(t) : "v"(d2), "v"(thr));
+}
+
 struct ConstsE { double r2, s_hphob, s_ion, s_polar; };  // wave-uniform: scalar registers
 
 DEVFN double words_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -184,10 +192,8 @@ DEVFN void store_batch_general(const Slots &sl, lmask m_valid, uint32_t n_rec, u
 // k_patch_deferred (pairs.inl).
 // Round 4 (scalar diet): one rare-path branch for "a probe decides" and "the square root needs the exact routine" together, the
 // allocator's common case in ~10 scalar instructions (alloc_take_e), masks straight out of the compares.
-// Round 4: the batch in two halves.  exact_issue_e reads the batch's queue entries and sends the neighbour gathers on their way; the caller
-// then runs the compaction rounds of the run's remaining survivors (which may overwrite the queue entries: they are in registers) and only
-// then exact_finish_e, so the L2 / HBM round trip of the gathers -- the longest single wait of a batch -- overlaps those rounds instead of
-// parking the wave (counters after the scalar diet: 54 % of wave-cycles at s_waitcnt).
+// The batch in two halves: exact_issue_e reads the batch's queue entries and sends the neighbour gathers on their way, exact_finish_e does
+// the rest (counters after the scalar diet: 54 % of wave-cycles at s_waitcnt).
 struct ExactRegs { uint32_t e; u32x4 bxy, bzp; unsigned long long kb; };
 template <bool FULL>
 DEVFN ExactRegs exact_issue_e(const WaveLdsE &w, const Sorted &so, uint32_t qoff, uint32_t count, uint32_t lane) {
@@ -441,7 +447,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
         }
         // per-lane constants of the prefilter: -2 h (exact in f32) and the threshold r2m - |h|^2, rounded up (DESIGN.md "Prefilter margin")
         const float3 hm2 = make_float3(-2.0f * home.x, -2.0f * home.y, -2.0f * home.z);
-        const float thr = __double2float_ru(r2m - ((double)home.x * home.x + (double)home.y * home.y + (double)home.z * home.z));
+        // (one ulp above the rounded-up threshold: the test below is the SIGN of acc - thr, which a tie would fail)
+        const float thr_ru = __double2float_ru(r2m - ((double)home.x * home.x + (double)home.y * home.y + (double)home.z * home.z));
+        const float thr = thr_ru > 0.0f ? __uint_as_float(__float_as_uint(thr_ru) + 1u) : (thr_ru < 0.0f ? __uint_as_float(__float_as_uint(thr_ru) - 1u) : 1e-37f);
         const uint32_t lane_tag = lane << kESlotBits;
         uint32_t qbyte = queue_lds;  // LDS byte address of the queue tail (wave-uniform): the phase-1 survivors waiting in w.queue; drained at the end of the task
 #pragma unroll 1
@@ -459,7 +467,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                 const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
                 if (!__any(len != 0u)) continue;
                 wave_lds_fence();  // previous chunk fully consumed
-                for (uint32_t p = cs + lane; p < ce; p += 64u) w.nrec[p - cs] = so.rec[p];
+                // Staging: both halves of the chunk requested before either is waited for (one round trip per chunk, not two), from clamped
+                // addresses (the pad of a short chunk holds copies of its last record: never inside a lane's window).
+                // (A software prefetch of the chunk's EXACT records here -- one word of each, coalesced, so that the survivors' gathers find
+                // their lines in the L2 -- was built and measured in round 4: 161-162 us with and without; the gathers' cost is their
+                // address work, 21 us per million wave-instructions, not the misses.  profiles/r04_emit_experiments.txt.)
+                {
+                    static_assert(kEChunk == 128u, "two staging loads per lane");
+                    const uint32_t p0 = min(cs + lane, ce - 1u), p1 = min(cs + lane + 64u, ce - 1u);
+                    const float4 r0 = so.rec[p0], r1 = so.rec[p1];
+                    w.nrec[lane] = r0; w.nrec[lane + 64u] = r1;
+                }
                 wave_lds_fence();
                 const uint32_t off = len ? j0 - cs : 0u;
                 uint32_t it0 = sub * kEAcc;  // (wave-uniform)  SPLIT == 8: the partner wave takes every other run of kEAcc tests
@@ -489,7 +507,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
 #pragma unroll
                             for (uint32_t u = 0; u < kReadAhead; ++u) acc[u] = __fmaf_rn(rz[u], hm2.z, acc[u]);
 #pragma unroll
-                            for (uint32_t u = 0; u < kReadAhead; ++u) push_pass(mask, acc[u], thr);
+                            for (uint32_t u = 0; u < kReadAhead; ++u) push_sign_e(mask, acc[u], thr);
                         }
                         nacc = (g + 1u) * kEGroup;
                         more = __any(it0 + nacc < len);
@@ -506,9 +524,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                         compact_rounds_e(mask, tag, qb, queue_lds + 256u);
                         while (qb >= queue_lds + 256u) {  // a full batch: the 64 entries at the tail; then the rest of the run's survivors
                             qb -= 256u;
+                            // (Finishing the batch only after the next compaction rounds -- the gathers in flight meanwhile -- was measured: no
+                            // gain, 162 us either way; the compiler then parks the next prefilter run on vmcnt(0) for a register it sees reused.)
                             const ExactRegs g = exact_issue_e<true>(w, so, qb - queue_lds, 64u, lane);
-                            compact_rounds_e(mask, tag, qb, queue_lds + 256u);  // (while the gathers are in flight)
                             exact_finish_e<true, ONLY, kChunkE>(g, K, tb, w, bl, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);
+                            compact_rounds_e(mask, tag, qb, queue_lds + 256u);
                         }
                         qbyte = qb;
                     }
