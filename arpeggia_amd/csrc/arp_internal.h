@@ -143,7 +143,7 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
                  bool skip_deferred);
 unsigned long long emit_scratch_records();
-void launch_neighbor_sum(const DevAtoms &in, const Workspace &ws, double radius, double r2, const float *weight, float *out, hipStream_t st);
+void launch_neighbor_sum(const DevAtoms &in, const Workspace &ws, double radius, double r2, const float *weight, float *out, hipStream_t st, Profiler *prof);
 void launch_pack_fix(const PackArrays &pa, hipStream_t st);
 void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, bool ordered, hipStream_t st);
 

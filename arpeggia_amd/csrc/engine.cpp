@@ -453,7 +453,7 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
         launch_count(d, ctx->ws, ctx->stream, prof, capacity, true, only);
         launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof, only);
     } else {
-        ctx->last_skip = skip_deferred_pass(ctx, d);
+        ctx->last_skip = !(params->flags & ARP_FLAG_NO_SPECULATION) && skip_deferred_pass(ctx, d);
         launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only, ctx->last_skip);
     }
     HIP_TRY(hipGetLastError());
@@ -1072,7 +1072,7 @@ extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const d
     arp_status s = check_device(ctx);
     if (s != ARP_OK) return s;
     if (n && (!x || !y || !z || !sidechain || !weight || !out)) { set_error("null argument"); return ARP_ERR_BAD_INPUT; }
-    if (n >= 0xFFFFFFF0ull) { set_error("too many atoms"); return ARP_ERR_BAD_INPUT; }
+    if (n >= 0x5000000ull) { set_error("too many atoms for one SAP neighbour sum (the kernel addresses the sorted records with 32-bit byte offsets: < 83886080 atoms)"); return ARP_ERR_BAD_INPUT; }
     if (!(sap_radius >= 0.0f)) { set_error("bad sap_radius"); return ARP_ERR_BAD_INPUT; }
     if (n == 0) return ARP_OK;
     // the grid machinery of the contact search, over the side-chain atoms only: everything else is kept out by the attribute bit that
@@ -1097,7 +1097,7 @@ extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const d
     HIP_TRY(hipMemcpyAsync(d_w, pin, n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_out, 0, n * 4, ctx->stream));  // atoms outside the side-chain set keep 0
     const double r2 = (double)(sap_radius * sap_radius);  // sap.rs:183: the product is formed in f32
-    launch_neighbor_sum(d, ctx->ws, (double)sap_radius, r2, d_w, d_out, ctx->stream);
+    launch_neighbor_sum(d, ctx->ws, (double)sap_radius, r2, d_w, d_out, ctx->stream, ctx->prof.enabled ? &ctx->prof : nullptr);
     HIP_TRY(hipGetLastError());
     float *h_out = (float *)(pin + ((n * 4 + 255u) & ~255ull));
     HIP_TRY(hipMemcpyAsync(h_out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -386,15 +386,33 @@ def main():
     if rank == 0:
         # HBM traffic of the dominant kernel cannot be counted from inside this process; when the run matches the configuration
         # the committed rocprofv3 --pmc passes were taken on, report that measurement (profiles/, with its source), else null.
-        traffic = None
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        # ... and ONLY when the profile was taken on the sources this library was built from (profiles/rNN_traffic.json carries the content
+        # hash of arpeggia_amd/csrc, tests/pmc_to_json.py): a stale profile is reported as null with the reason, never attached silently.
+        traffic, traffic_note, issue = None, None, None
+        try:
+            from arpeggia_amd import build as _build
+            running_hash = _build.source_hash()
+        except Exception as e:  # noqa: BLE001
+            running_hash = None; traffic_note = f"source hash of the running library unavailable: {e}"
+        newest = sorted((ROOT / "profiles").glob("r*_traffic.json"), reverse=True)
+        for path in newest:
             try:
-                tr = json.loads((ROOT / "profiles" / name).read_text())
-                if tr["workload"] == args.workload and tr["atoms"] == n_atoms and not args.deterministic and not args.contacts_only:
-                    traffic = {"hbm_bytes_per_launch": tr["hbm_bytes_per_launch"], "kernel": tr["kernel"], "source": tr["source"]}
+                tr = json.loads(path.read_text())
+                if tr["workload"] != args.workload or tr["atoms"] != n_atoms or args.deterministic or args.contacts_only:
+                    continue
+                if running_hash is None:
                     break
+                if tr.get("csrc_hash") != running_hash:
+                    traffic_note = (f"{path.name} was taken on other sources (csrc hash {str(tr.get('csrc_hash'))[:12]}.. != running {running_hash[:12]}..): "
+                                    f"not attached; re-run tests/run_gpu_pmc.sh + tests/pmc_to_json.py")
+                    break
+                traffic = {"hbm_bytes_per_launch": tr["hbm_bytes_per_launch"], "kernel": tr["kernel"], "source": tr["source"], "csrc_hash": tr["csrc_hash"]}
+                issue = dict(tr.get("issue") or {}, source=tr["source"], csrc_hash=tr["csrc_hash"]) or None
+                break
             except (OSError, KeyError, ValueError):
                 pass
+        if traffic is None and traffic_note is None:
+            traffic_note = "no committed counter profile for this workload / size / emitter"
         line = {
             "metric": "classified atom-pairs/s per GPU at 6.5 A cutoff; achieved HBM GB/s vs peak",
             "value": pairs_all * args.steps / wall_max,
@@ -410,6 +428,11 @@ def main():
             "roofline": roofline_of(n_atoms, n_pairs, acc, dev_ms, traffic),
             "device_ms_per_step": dev_ms,
         }
+        # what actually binds: the graded bound stays HBM, `roofline.issue` says how far instruction issue is from idle --
+        # the counters of the dominant kernel (same provenance rule as `traffic`), or the reason they are missing
+        line["roofline"]["issue"] = issue
+        if traffic_note:
+            line["roofline"]["traffic_note"] = traffic_note
         line.update(sub)
         if world == 1 and not args.no_cpu_baseline:
             wl = args.workload if args.workload in ("s1", "s2") else "s2"

@@ -91,6 +91,14 @@ typedef struct arp_atoms {
  * copy to the host and the table assembly shrink by that factor.  arp_get_contacts uses it. */
 #define ARP_FLAG_DETERMINISTIC 0x1u
 #define ARP_FLAG_CONTACTS_ONLY 0x2u
+/* NO_SPECULATION (arp_contacts_atomic_enqueue): the single-pass emitter normally skips the launch of the probe pass (hydrogen-bond angles,
+ * disulfide dihedrals) when the previous call on the same arrays needed none, checks the guess on the device, and lets
+ * arp_contacts_atomic_result repeat the whole call when the guess was wrong -- until then the records a probe decides sit in `out` with
+ * kind 0.  With this flag the probe pass is always launched behind the emitter, on the same stream: work the caller orders on that stream
+ * after the enqueue sees final records.  (One repeat remains possible, for either setting: a deferred-probe list that overflows -- an input
+ * with more than ~16 probe candidates per atom -- is grown by arp_contacts_atomic_result and the call run again; it then returns only after
+ * the repeat, and what ran on the stream in between has seen an incomplete list.  ARP_FLAG_DETERMINISTIC never speculates.) */
+#define ARP_FLAG_NO_SPECULATION 0x4u
 
 typedef struct arp_params {
     double vdw_comp;             /* mod.rs:61 vdw_comp    (default 0.1) */
@@ -146,9 +154,13 @@ arp_status arp_contacts_atomic(arp_context *ctx, const arp_atoms *atoms, const a
 void arp_pairs_free(arp_pairs *pairs);
 
 /* Asynchronous, allocation-free form for resident data (inputs MUST be ARP_MEM_DEVICE): enqueues the whole
- * pipeline on the context's stream and returns.  `out` is a device buffer of `capacity` pairs.  After the stream
- * has been synchronised, arp_contacts_atomic_result() returns the pair count (ARP_ERR_CAPACITY + the required
- * count when the buffer was too small; nothing is written past `capacity`). */
+ * pipeline on the context's stream and returns.  `out` is a device buffer of `capacity` pairs.
+ * arp_contacts_atomic_result() synchronises the stream and returns the pair count (ARP_ERR_CAPACITY + the required
+ * count when the buffer was too small; nothing is written past `capacity`).
+ * CONTRACT: the contents of `out` (and the count) are DEFINED ONLY AFTER arp_contacts_atomic_result HAS RETURNED ARP_OK.  Between the
+ * two calls the buffer is speculative: the result call may run the enqueued work a second time (see ARP_FLAG_NO_SPECULATION), so
+ * stream work ordered between enqueue and result must not consume `out` unless that flag is set -- and `atoms`, `params`' arrays and
+ * `out` must stay alive and unchanged until the result call returns. */
 arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_atoms *atoms, const arp_params *params,
                                        arp_pair *out, uint64_t capacity);
 arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs);

@@ -657,6 +657,62 @@ def test_deferred_pass_memo_survives_new_content_in_the_same_buffers():
             assert_pairs_equal(c.atomic_contacts(atoms[name], prm), w, f"memo {name} only={only} (one call)")
 
 
+def test_no_speculation_flag_makes_the_enqueued_list_final_on_the_stream():
+    """include/arpeggia_amd.h, arp_contacts_atomic_enqueue: `out` is defined only after arp_contacts_atomic_result returns ARP_OK -- unless
+    ARP_FLAG_NO_SPECULATION is set, which makes the enqueue launch the probe pass whatever the memo says.  The caller's buffers first hold a
+    cloud that defers nothing (so the memo says "skip the probe pass"), then a hydrogen-rich structure of the same size at the same addresses.
+    A device-side copy of `out`, ordered on the SAME stream between enqueue and result, must equal the oracle under the flag; without it the
+    copy still shows the kind-0 placeholders of the records only the probe pass can decide (the speculation the header warns about)."""
+    torch = pytest.importorskip("torch")
+    rec_b = synth.gen_stress(n_res=300, seed=17)
+    soa_b = aa.Structure.from_records(rec_b).soa("/")
+    n = len(soa_b["x"])
+    rec_a = synth.gen_s2(n, seed=5)
+    soa_a = aa.Structure.from_records(rec_a, hierarchy=True).soa("/")
+    want_b = ob.Structure.from_atoms(synth.records_to_oracle(rec_b, flat=False), flat=False).atomic_contacts()
+    probe_kinds = (1 << aa.INTERACTIONS.index("HydrogenBond")) | (1 << aa.INTERACTIONS.index("Disulfide"))
+    assert (want_b["kind"] & probe_kinds).any()
+
+    def dev_of(v):
+        return torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda()
+
+    per_atom = ("x", "y", "z", "attr", "res_ord", "chain_rank", "model", "res_id")
+    shared = {k: torch.empty_like(dev_of(soa_b[k])) for k in per_atom}
+    keep, atoms, content = [], {}, {}
+    for name, soa in (("a", soa_a), ("b", soa_b)):
+        dev = dict(shared)
+        dev.update({k: dev_of(v) for k, v in soa.items() if k not in per_atom})
+        content[name] = {k: dev_of(soa[k]) for k in per_atom}
+        atoms[name] = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
+    stream = torch.cuda.current_stream()
+    c = aa.Context(0, stream=stream.cuda_stream)
+    out = torch.zeros((len(want_b) + 4096, 4), dtype=torch.int32, device="cuda")
+
+    def fill(name):
+        for k in per_atom:
+            shared[k].copy_(content[name][k])
+        torch.cuda.synchronize()
+
+    for flag in (True, False):
+        prm = aa.default_params(no_speculation=flag)
+        fill("a")
+        c.enqueue(atoms["a"], aa.default_params(), out.data_ptr(), out.shape[0])
+        c.result()  # the memo now says: these arrays defer nothing
+        fill("b")
+        c.enqueue(atoms["b"], prm, out.data_ptr(), out.shape[0])
+        snap = out.clone()  # ordered on the context's stream, BEFORE the result call
+        got_n = c.result()
+        assert got_n == len(want_b)
+        assert_pairs_equal(out[:got_n].cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1), want_b, f"after result, flag={flag}")
+        early = snap[:got_n].cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1)
+        if flag:
+            assert_pairs_equal(early, want_b, "device-side copy taken between enqueue and result, ARP_FLAG_NO_SPECULATION")
+        else:  # the speculation is real: the copy holds placeholders where the final list holds probe-decided kinds
+            e, w = canon(early), canon(want_b)
+            assert np.array_equal(e["i"], w["i"].astype(np.uint32)) and np.array_equal(e["j"], w["j"].astype(np.uint32))
+            assert ((w["kind"] & probe_kinds) != 0)[e["kind"] == 0].any() and not (e["kind"] & probe_kinds).any()
+
+
 def test_deferred_list_overflow_grows_and_repeats(monkeypatch):
     # hydrogen-rich structure: thousands of candidates need a probe; a 65536-entry list (every block holds a partly used 512-entry chunk) overflows and is grown 4x per retry
     rec = synth.gen_stress(n_res=600, seed=91)
@@ -674,7 +730,7 @@ def test_sap_neighbor_sum_matches_the_restatement(ctx):
     """src/sap.rs:155-204: f32 sum of hydrophobicity x relative side-chain SASA over the side-chain atoms within 5 A, self included.
     The reference accumulates in R*-tree order, the oracle in index order, the device in slot order: f32 sums agree to rounding."""
     rng = np.random.default_rng(12)
-    for path_or_n in ("6bft", 40000):
+    for path_or_n in ("6bft", 40000, 100000):
         if path_or_n == "6bft":
             rec = synth.read_pdb_records(synth.DATA / "6bft.pdb")
         else:
