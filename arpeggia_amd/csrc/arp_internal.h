@@ -20,6 +20,7 @@ struct DevParams {
     double s_cov[256];    // lt(cov[a]+cov[b] + c)   vdw.rs:34
     double s_vdw[256];    // lt(vdw[a]+vdw[b] + c)   vdw.rs:41
     double s_hacc[16];    // le(h_vdw + vdw[acceptor] + c)   hbond.rs:54,98
+    double s_cov_max;     // the largest s_cov[] of all element pairs: below it a candidate MAY be inside a covalent / clash band (k_emit's short level count)
     float r2f;            // prefilter threshold in f32 (r2 + margin), set by the grid setup kernel
     uint32_t flags;       // arp_params.flags (ARP_FLAG_CONTACTS_ONLY is read by the pair kernels)
 };

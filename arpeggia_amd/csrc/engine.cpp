@@ -89,6 +89,8 @@ void make_dev_params(const arp_params &p, DevParams *d) {
         }
         d->s_hacc[a] = bound_le(p.h_vdw_radius + p.vdw_radius[a] + c);  // hbond.rs:54
     }
+    d->s_cov_max = 0.0;
+    for (int k = 0; k < 256; k++) d->s_cov_max = std::max(d->s_cov_max, d->s_cov[k]);  // (s_cov >= s_clash after the clamp above)
     d->r2f = (float)d->r2;
     d->flags = p.flags;
 }

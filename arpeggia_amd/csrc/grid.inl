@@ -175,6 +175,17 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
         acc.models = max(acc.models, (uint32_t)p[6]); acc.bad |= (uint32_t)p[7];
     }
     box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
+    // the largest covalent bound among the element pairs that are PRESENT (k_emit's short level count: a candidate above it is in no
+    // covalent or clash band; the parameter table also holds the metals' radii, which would put every other candidate below it)
+    {
+        __shared__ double s_cmax[4];
+        const uint32_t present = (acc.bad >> 8) & 0xFFFFu, ea = threadIdx.x >> 4, eb = threadIdx.x & 15u;
+        double b = ((present >> ea) & (present >> eb) & 1u) ? prm->s_cov[threadIdx.x] : 0.0;
+        for (int off = 32; off; off >>= 1) b = fmax(b, __shfl_xor(b, off));
+        if ((threadIdx.x & 63) == 0) s_cmax[threadIdx.x >> 6] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) prm->s_cov_max = fmax(fmax(s_cmax[0], s_cmax[1]), fmax(s_cmax[2], s_cmax[3]));
+    }
     // ARP_FLAG_CONTACTS_ONLY: no rule can match beyond the largest decision bound of the element pairs that are present
     // (every rule of classify() is `s < bound`), so the search radius shrinks to it -- for C/N/O/S that is the 4.5 A of the
     // hydrophobic rule -- and the dropped candidates are exactly ones the flag would have filtered out.

@@ -117,7 +117,7 @@ DEVFN void push_sign_e(uint32_t &mask, float d2, float thr) {
     asm("v_sub_f32 %1, %2, %3\n\tv_alignbit_b32 %0, %0, %1, 31" : "+v"(mask), "=&v"(t) : "v"(d2), "v"(thr));
 }
 
-struct ConstsE { double r2, s_hphob, s_ion, s_polar; };  // wave-uniform: scalar registers
+struct ConstsE { double r2, s_hphob, s_ion, s_polar, s_cov_max; };  // wave-uniform: scalar registers
 
 DEVFN double words_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
@@ -135,6 +135,7 @@ typedef unsigned long long lmask;
         return m;                                                                                                \
     }
 ARP_LMASK_CMP(lm_ge_f64_sv, "v_cmp_ge_f64", double, "s", double, "v")      // a (scalar) >= b
+ARP_LMASK_CMP(lm_gt_f64_sv, "v_cmp_gt_f64", double, "s", double, "v")      // a (scalar) >  b
 ARP_LMASK_CMP(lm_lt_u32_sv, "v_cmp_lt_u32", uint32_t, "s", uint32_t, "v")  // a (scalar) <  b
 ARP_LMASK_CMP(lm_gt_u32_sv, "v_cmp_gt_u32", uint32_t, "s", uint32_t, "v")  // a (scalar) >  b
 ARP_LMASK_CMP(lm_ne_u32, "v_cmp_ne_u32", uint32_t, "v", uint32_t, "v")
@@ -253,37 +254,64 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
         if (__builtin_expect(n_rec == 0u, 0)) return;
         a_old = alloc_issue_e(bl.alloc_state, n_rec);
     }
-    // distance levels: Le against the element pair's bounds, Lg against the fixed ones; L = 4 Le + Lg
+    // distance levels: Le against the element pair's bounds {vdw, cov, clash}, Lg against the fixed ones {4.5, 4.0, 3.5}; L = 4 Le + Lg.
+    // All candidates (!ONLY): only the van-der-Waals bound on the common path -- a distance below the covalent or the clash bound of ITS
+    // element pair is first of all below the largest covalent bound of any pair (K.s_cov_max, a scalar), which hardly any candidate is
+    // (the atoms of one residue and of sequence neighbours never pair, complex.rs:108-113); those batches recompute the levels in full on
+    // the general path below.  Two LDS reads and four half-rate vector instructions less per batch.
     const uint32_t eix = (pa & 0xF0u) | (pb & 0x0Fu);
-    const double t_clash = tb.s_clash[eix], t_cov = tb.s_cov[eix], t_vdw = tb.s_vdw[eix];
+    const double t_vdw = tb.s_vdw[eix];
     uint32_t L = 0;
-    asm("v_cmp_lt_f64_e32 vcc, %[s], %[tv]\n\t"
-        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
-        "v_cmp_lt_f64_e32 vcc, %[s], %[tc]\n\t"
-        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
-        "v_cmp_lt_f64_e32 vcc, %[s], %[tx]\n\t"
-        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
-        "v_lshlrev_b32_e32 %[L], 2, %[L]\n\t"
-        "v_cmp_gt_f64_e32 vcc, %[k45], %[s]\n\t"
-        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
-        "v_cmp_gt_f64_e32 vcc, %[k40], %[s]\n\t"
-        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
-        "v_cmp_gt_f64_e32 vcc, %[k35], %[s]\n\t"
-        "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc"
-        : [L] "+v"(L)
-        : [s] "v"(s), [tv] "v"(t_vdw), [tc] "v"(t_cov), [tx] "v"(t_clash), [k45] "s"(K.s_hphob), [k40] "s"(K.s_ion), [k35] "s"(K.s_polar)
-        : "vcc");
+    lmask m_close = 0ull;
+    auto levels_full = [&]() {
+        const double t_clash = tb.s_clash[eix], t_cov = tb.s_cov[eix];
+        uint32_t Lf = 0;
+        asm("v_cmp_lt_f64_e32 vcc, %[s], %[tv]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_cmp_lt_f64_e32 vcc, %[s], %[tc]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_cmp_lt_f64_e32 vcc, %[s], %[tx]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_lshlrev_b32_e32 %[L], 2, %[L]\n\t"
+            "v_cmp_gt_f64_e32 vcc, %[k45], %[s]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_cmp_gt_f64_e32 vcc, %[k40], %[s]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_cmp_gt_f64_e32 vcc, %[k35], %[s]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc"
+            : [L] "+v"(Lf)
+            : [s] "v"(s), [tv] "v"(t_vdw), [tc] "v"(t_cov), [tx] "v"(t_clash), [k45] "s"(K.s_hphob), [k40] "s"(K.s_ion), [k35] "s"(K.s_polar)
+            : "vcc");
+        return Lf;
+    };
+    if (ONLY) {
+        L = levels_full();
+    } else {
+        asm("v_cmp_lt_f64_e32 vcc, %[s], %[tv]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_lshlrev_b32_e32 %[L], 2, %[L]\n\t"
+            "v_cmp_gt_f64_e32 vcc, %[k45], %[s]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_cmp_gt_f64_e32 vcc, %[k40], %[s]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
+            "v_cmp_gt_f64_e32 vcc, %[k35], %[s]\n\t"
+            "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc"
+            : [L] "+v"(L)
+            : [s] "v"(s), [tv] "v"(t_vdw), [k45] "s"(K.s_hphob), [k40] "s"(K.s_ion), [k35] "s"(K.s_polar)
+            : "vcc");
+        m_close = lm_gt_f64_sv(K.s_cov_max, s) & m_valid;
+    }
     // W = (Pa & Qb) | (Pb & Qa): P is byte 1 of the pair word, Q byte 2
     uint32_t w1, w2;
     asm("v_and_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
         "v_and_b32_sdwa %1, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2"
         : "=&v"(w1), "=&v"(w2) : "v"(pa), "v"(pb));
-    const uint32_t t = tb.lut[(L << 7) | w1 | w2];
+    uint32_t t = tb.lut[(L << 7) | w1 | w2];
     // a probe decides: bit 30 & (either residue carries hydrogens), bit 29 & (residue tables present); bit 31 is never set
     lmask m_rare = lm_lt_u32_sv(0x1FFFFFFFu, t & (pa | pb | probe_bits));  // (& m_valid below)
     uint32_t kind = t & 0x1FFFFFFFu;
     if (ONLY) m_valid &= lm_lt_u32_sv(0u, kind) | m_rare;  // no-interaction candidates are dropped
-    const lmask m_defer = m_rare & m_valid;
+    lmask m_defer = m_rare & m_valid;
     // (f32) of the correctly rounded f64 sqrt (kernels.hip dist_f32), the rare exact path behind a wave-uniform branch
     const double r = (double)__frsqrt_rn((float)s);
     const double y0 = s * r, hr = 0.5 * r;
@@ -299,7 +327,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
     u32x4 rec;
     rec.x = lm_select(m_swap, bzp.w, azp.w); rec.y = lm_select(m_swap, azp.w, bzp.w);
     uint32_t general;  // (wave-uniform, and opaque to the optimiser in both arms: as a bool it comes back as a lane mask + three scalar instructions per use)
-    if (__builtin_expect((m_exact | m_defer) == 0ull, 1)) {
+    if (__builtin_expect((m_exact | m_defer | m_close) == 0ull, 1)) {
         rec.z = __float_as_uint((float)y);
         rec.w = kind;
         if (ONLY) { if (n_rec == 0u) return; }
@@ -333,6 +361,11 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
         asm volatile("" ::: "memory");  // keep this a branch (no speculation of the long sequence)
         if (m_exact) { if (lm_lane(m_exact, lane)) y = sqrt(s); }
         rec.z = __float_as_uint((float)y);
+        if (!ONLY && m_close) {  // a candidate inside the covalent range of some element pair: the levels in full, and what follows from them
+            t = tb.lut[(levels_full() << 7) | w1 | w2];
+            kind = t & 0x1FFFFFFFu;
+            m_defer = lm_lt_u32_sv(0x1FFFFFFFu, t & (pa | pb | probe_bits)) & m_valid;
+        }
         asm volatile("s_mov_b32 %0, 1" : "=s"(general));
     }
     if (__builtin_expect(general != 0u, 0)) {  // ---- chunk crossing / refill / scratch / a probe decides: the general placement ----
@@ -391,7 +424,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
     const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
     const uint32_t probe_bits = in.n_res != 0u ? (1u << 29) : 0u;  // residue tables present: CYS SG pairs in the covalent band get their dihedral probe
-    const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar};
+    const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar, dprm->s_cov_max};
     const double r2m = gp->r2m;
     // chunks that lie wholly inside the caller's buffer: a batch placed in one of them needs no further capacity test (alloc_take_e)
     // (and inside its first 2^32 bytes: the fast path addresses with a 32-bit byte offset; what lies beyond takes the general path)

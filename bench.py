@@ -270,9 +270,12 @@ def main():
     prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only)
     check = not args.no_check
 
+    recs = {}  # (workload, atoms) -> the generated records (the SAP leg reuses the S1 clouds)
+
     def cloud(workload, atoms=None):  # one structure per rank, its own seed: independent structures shard with no exchange
         atoms = atoms or args.atoms
         rec = getattr(synth, f"gen_{workload}")(atoms, seed=SEED + (4 if workload == "s2" else 3) + 1000 * rank + (0 if atoms == args.atoms else 7))
+        recs[(workload, atoms)] = rec
         order = os.environ.get("ARP_BENCH_ORDER")  # diagnostic: the same cloud with its atoms in another input order
         if order:
             import numpy as np
@@ -343,6 +346,14 @@ def main():
                                    "table_rows": int(len(table["model"])), "get_contacts_warm_us": best * 1e6}
                 sub["files"] = {"workload": "tests/data/1ubq.pdb and 6bft.pdb (= the reference's test-data), groups='/', vdw_comp=0.1, dist_cutoff=6.5: the pair pass on "
                                             "device-resident arrays (200 calls on the stream) and the whole table (arp_get_contacts, best of 20 warm calls, host wall)", **files}
+            if rank == 0:  # the SAP neighbour sum on the same S1 clouds (device time of the grid build + sum kernel per call)
+                import sap_timing
+
+                sap_ctx = aa.Context(dev_index)
+                sub["sap"] = {"workload": "arp_sap_neighbor_sum on the S1 clouds, radius 5 A, side-chain atoms only in the grid; per-kernel HIP events, host staging "
+                                          "and PCIe excluded; algorithmic bytes 36 B read + 4 B written per side-chain atom",
+                              **{f"s1_{a}": sap_timing.measure(sap_ctx, a, rec=recs.get(("s1", a))) for a in (100_000, args.atoms)}}
+                del sap_ctx
             packs, n_mine = batch(1250 * world)
             wb, db, pb, ab, nb = measure_resident(aa, _lib, torch, dev, dev_index, packs[0], prm, args.steps, args.warmup, args.profile_steps, barrier, check)
             wbmax, pball = reduce_job(dist, red_dev, wb, pb)

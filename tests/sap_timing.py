@@ -11,8 +11,8 @@ import arpeggia_amd as aa  # noqa: E402
 import synth  # noqa: E402
 
 
-def measure(ctx, n_atoms, reps=5):
-    rec = synth.gen_s1(n_atoms)
+def measure(ctx, n_atoms, reps=5, rec=None):
+    rec = synth.gen_s1(n_atoms) if rec is None else rec
     n = len(rec["x"])
     backbone = np.isin(rec["name"], [b"N", b"CA", b"C", b"O", b"OXT"])
     side = (~backbone) & (rec["resn"] != b"HOH") & (rec["element"] != b"H")
