@@ -190,7 +190,7 @@ class Structure:
         out = {
             "x": _np_from(v.x, n, "<f8"), "y": _np_from(v.y, n, "<f8"), "z": _np_from(v.z, n, "<f8"),
             "attr": _np_from(v.attr, n, "<u4"), "res_ord": _np_from(v.res_ord, n, "<u4"),
-            "chain_rank": _np_from(v.chain_rank, n, "<u2"), "model": _np_from(v.model, n, "<u2"),
+            "chain_rank": _np_from(v.chain_rank, n, "<u4"), "model": _np_from(v.model, n, "<u4"),
             "res_id": _np_from(v.res_id, n, "<u4"),
             "res_h_ptr": _np_from(v.res_h_ptr, nr + 1 if nr else 0, "<u4"),
             "res_cb": _np_from(v.res_cb, nr, "<u4"), "res_sg": _np_from(v.res_sg, nr, "<u4"),
@@ -221,7 +221,7 @@ def atoms_from_arrays(soa: dict, location: int = _lib.ARP_MEM_HOST, keep: list |
     v.n = int(x.numel() if hasattr(x, "numel") else len(x))
     v.x, v.y, v.z = ptr("x", "<f8"), ptr("y", "<f8"), ptr("z", "<f8")
     v.attr, v.res_ord = ptr("attr", "<u4"), ptr("res_ord", "<u4")
-    v.chain_rank, v.model = ptr("chain_rank", "<u2"), ptr("model", "<u2")
+    v.chain_rank, v.model = ptr("chain_rank", "<u4"), ptr("model", "<u4")
     rcb = soa.get("res_cb")
     v.n_res = int((rcb.numel() if hasattr(rcb, "numel") else len(rcb))) if rcb is not None else 0
     if v.n_res:

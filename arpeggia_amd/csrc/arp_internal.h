@@ -51,7 +51,7 @@ struct DevAtoms {
     uint32_t n;
     const double *x, *y, *z;
     const uint32_t *attr, *res_ord;
-    const uint16_t *chain_rank, *model;
+    const uint32_t *chain_rank, *model;
     const uint32_t *res_id, *res_h_ptr, *res_h_idx, *res_cb, *res_sg;
     uint32_t n_res;
     uint32_t per_model;   // packed batch: size the grid by the largest member and give every model its own origin
@@ -67,7 +67,8 @@ struct DevAtoms {
 struct __attribute__((aligned(16))) Fat {
     double x, y;
     double z; uint32_t pw, orig /* index into the caller's arrays */;
-    uint32_t res_ord, crm /* chain_rank | model << 16 */, cell /* cell id of the slot */, attr;
+    uint32_t res_ord, crm /* chain rank (all 32 bits; the model is not in the key: every model owns its own slab of the grid + an empty
+                             separator layer, so the windows of an atom only ever hold atoms of its own model, complex.rs:96-98) */, cell /* cell id of the slot */, attr;
 };
 constexpr uint32_t kPwLigand = 1u << 24, kPwReceptor = 1u << 25, kPwResHasH = 1u << 30;  // (bits 26-29 and 31 stay clear: the emit kernel ANDs the word with a table entry's probe bits)
 
@@ -119,7 +120,7 @@ struct PackDesc {             // entry m of K + 1 (the last one is the sentinel 
 struct PackArrays {
     uint32_t n, n_res, n_h, K;
     PackDesc *desc;
-    uint16_t *model;
+    uint32_t *model;
     uint32_t *res_id, *res_h_ptr, *res_cb, *res_sg, *res_h_idx;
     uint32_t *n_models, *status;             // K, 1
     unsigned long long *count, *offset, *cursor;  // K, K + 1, K

@@ -27,12 +27,12 @@ DEVFN uint32_t lane_owner(const PackDesc *desc, uint32_t K, uint32_t i, bool hav
     return (i >= c.lo && i < c.hi) ? c.m : pack_owner(desc, K, i, &PackDesc::first_atom);
 }
 // models per member (max ordinal + 1): one atomic per run of same-owner atoms in a wave (members are contiguous)
-__global__ __launch_bounds__(256) void k_pack_models(uint32_t n, uint32_t K, const PackDesc *desc, const uint16_t *model, uint32_t *n_models) {
+__global__ __launch_bounds__(256) void k_pack_models(uint32_t n, uint32_t K, const PackDesc *desc, const uint32_t *model, uint32_t *n_models) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     uint32_t own = ARP_NONE, m = 0;
     OwnerCache oc;
     own = lane_owner(desc, K, i, i < n, oc);
-    if (i < n) m = (uint32_t)model[i] + 1u;
+    if (i < n) m = min(model[i], 0xFFFFFFFEu) + 1u;
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)own);
     if (__all(own == first || own == ARP_NONE)) {  // the common case: the whole wave belongs to one member
         const uint32_t mx = wave_max_u32(own == ARP_NONE ? 0u : m);
@@ -42,13 +42,13 @@ __global__ __launch_bounds__(256) void k_pack_models(uint32_t n, uint32_t K, con
     }
 }
 
-// exclusive scan of the per-member counts into desc[m].model_off (K <= 65535: one block); total > 65535 models cannot be
-// told apart in the 16-bit model field -> status word 1
+// exclusive scan of the per-member counts into desc[m].model_off (K <= 65535: one block); a pack of more than 65535 models does not
+// fit the per-model boxes of the workspace (Workspace::model_box) -> status word 1 (the members then run one by one)
 __global__ __launch_bounds__(1024) void k_pack_scan(uint32_t K, const uint32_t *n_models, PackDesc *desc, uint32_t *status) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (K + 1023u) / 1024u, lo = min(K, threadIdx.x * per), hi = min(K, lo + per);
     uint32_t s = 0;
-    for (uint32_t m = lo; m < hi; m++) s += n_models[m];
+    for (uint32_t m = lo; m < hi; m++) s += min(n_models[m], 0x10000u);  // (saturating: a member with 2^32 - 1 models must not wrap the total back into range)
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -63,14 +63,14 @@ __global__ __launch_bounds__(1024) void k_pack_scan(uint32_t K, const uint32_t *
 }
 
 // renumber in place: models and residue ids per atom, hydrogen-list offsets and CB / SG atom indices per residue, atom indices per hydrogen
-__global__ __launch_bounds__(256) void k_pack_fix(uint32_t n, uint32_t n_res, uint32_t n_h, uint32_t K, const PackDesc *desc, uint16_t *model, uint32_t *res_id,
+__global__ __launch_bounds__(256) void k_pack_fix(uint32_t n, uint32_t n_res, uint32_t n_h, uint32_t K, const PackDesc *desc, uint32_t *model, uint32_t *res_id,
                                                   uint32_t *res_h_ptr, uint32_t *res_cb, uint32_t *res_sg, uint32_t *res_h_idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     OwnerCache oc;
     const uint32_t own = lane_owner(desc, K, i, i < n, oc);
     if (i < n) {
         const PackDesc d = desc[own];
-        model[i] = (uint16_t)(model[i] + d.model_off);
+        model[i] = model[i] + d.model_off;
         res_id[i] += d.first_res;
     }
     if (i < n_res) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_scatter(const unsigned 
 void launch_pack_fix(const PackArrays &pa, hipStream_t st) {
     const uint32_t nb = (std::max(std::max(pa.n, pa.n_res + 1u), pa.n_h) + 255u) / 256u;
     (void)hipMemsetAsync(pa.n_models, 0, sizeof(uint32_t) * pa.K, st);
-    hipLaunchKernelGGL(k_pack_models, dim3((pa.n + 255u) / 256u), dim3(256), 0, st, pa.n, pa.K, (const PackDesc *)pa.desc, (const uint16_t *)pa.model, pa.n_models);
+    hipLaunchKernelGGL(k_pack_models, dim3((pa.n + 255u) / 256u), dim3(256), 0, st, pa.n, pa.K, (const PackDesc *)pa.desc, (const uint32_t *)pa.model, pa.n_models);
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pa.K, (const uint32_t *)pa.n_models, pa.desc, pa.status);
     hipLaunchKernelGGL(k_pack_fix, dim3(nb ? nb : 1u), dim3(256), 0, st, pa.n, pa.n_res, pa.n_h, pa.K, (const PackDesc *)pa.desc, pa.model, pa.res_id, pa.res_h_ptr, pa.res_cb,
                        pa.res_sg, pa.res_h_idx);

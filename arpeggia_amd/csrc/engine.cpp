@@ -296,8 +296,8 @@ static arp_status stage_inputs(arp_context *ctx, const arp_atoms *a, DevAtoms *d
     // layout of the block: 256-byte aligned segments
     struct Seg { const void *src; uint64_t bytes, off; };
     const uint64_t n = a->n, nr = a->n_res;
-    Seg seg[12] = {{a->x, n * 8, 0}, {a->y, n * 8, 0}, {a->z, n * 8, 0}, {a->attr, n * 4, 0}, {a->res_ord, n * 4, 0}, {a->chain_rank, n * 2, 0},
-                   {a->model, n * 2, 0}, {nr ? a->res_id : nullptr, nr ? n * 4 : 0, 0}, {nr ? a->res_h_ptr : nullptr, nr ? (nr + 1) * 4 : 0, 0},
+    Seg seg[12] = {{a->x, n * 8, 0}, {a->y, n * 8, 0}, {a->z, n * 8, 0}, {a->attr, n * 4, 0}, {a->res_ord, n * 4, 0}, {a->chain_rank, n * 4, 0},
+                   {a->model, n * 4, 0}, {nr ? a->res_id : nullptr, nr ? n * 4 : 0, 0}, {nr ? a->res_h_ptr : nullptr, nr ? (nr + 1) * 4 : 0, 0},
                    {nr ? a->res_cb : nullptr, nr * 4, 0}, {nr ? a->res_sg : nullptr, nr * 4, 0}, {nh ? a->res_h_idx : nullptr, nh * 4, 0}};
     uint64_t total = 0;
     for (Seg &g : seg) { g.off = total; total += (g.bytes + 255u) & ~255ull; }
@@ -315,7 +315,7 @@ static arp_status stage_inputs(arp_context *ctx, const arp_atoms *a, DevAtoms *d
     auto at = [&](int k) -> const void * { return s.dev + seg[k].off; };
     d->x = (const double *)at(0); d->y = (const double *)at(1); d->z = (const double *)at(2);
     d->attr = (const uint32_t *)at(3); d->res_ord = (const uint32_t *)at(4);
-    d->chain_rank = (const uint16_t *)at(5); d->model = (const uint16_t *)at(6);
+    d->chain_rank = (const uint32_t *)at(5); d->model = (const uint32_t *)at(6);
     d->res_id = (const uint32_t *)at(7); d->res_h_ptr = (const uint32_t *)at(8); d->res_cb = (const uint32_t *)at(9); d->res_sg = (const uint32_t *)at(10);
     d->res_h_idx = (const uint32_t *)at(11);
     return ARP_OK;
@@ -717,7 +717,7 @@ struct PackLayout {
     enum { X, Y, Z, ATTR, RES_ORD, CHAIN, MODEL, RES_ID, RES_H_PTR, RES_CB, RES_SG, RES_H_IDX, DESC, N_MODELS, STATUS, COUNT, OFFSET, CURSOR, N_SEG };
     uint64_t off[N_SEG], upload = 0, total = 0;
     PackLayout(uint64_t n, uint64_t nr, uint64_t nh, uint64_t K) {
-        const uint64_t bytes[N_SEG] = {n * 8, n * 8, n * 8, n * 4, n * 4, n * 2, n * 2, n * 4, (nr + 1) * 4, nr * 4, nr * 4, nh * 4, (K + 1) * 16,
+        const uint64_t bytes[N_SEG] = {n * 8, n * 8, n * 8, n * 4, n * 4, n * 4, n * 4, n * 4, (nr + 1) * 4, nr * 4, nr * 4, nh * 4, (K + 1) * 16,
                                        K * 4, 256, K * 8, (K + 1) * 8, K * 8};
         uint64_t t = 0;
         for (int k = 0; k < N_SEG; k++) { off[k] = t; t += (bytes[k] + 255u) & ~255ull; if (k == DESC) upload = t; }
@@ -855,7 +855,7 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
         memcpy(seg(PackLayout::X) + 8ull * d.first_atom, a.x, a.n * 8); memcpy(seg(PackLayout::Y) + 8ull * d.first_atom, a.y, a.n * 8);
         memcpy(seg(PackLayout::Z) + 8ull * d.first_atom, a.z, a.n * 8);
         memcpy(seg(PackLayout::ATTR) + 4ull * d.first_atom, a.attr, a.n * 4); memcpy(seg(PackLayout::RES_ORD) + 4ull * d.first_atom, a.res_ord, a.n * 4);
-        memcpy(seg(PackLayout::CHAIN) + 2ull * d.first_atom, a.chain_rank, a.n * 2); memcpy(seg(PackLayout::MODEL) + 2ull * d.first_atom, a.model, a.n * 2);
+        memcpy(seg(PackLayout::CHAIN) + 4ull * d.first_atom, a.chain_rank, a.n * 4); memcpy(seg(PackLayout::MODEL) + 4ull * d.first_atom, a.model, a.n * 4);
         memcpy(seg(PackLayout::RES_ID) + 4ull * d.first_atom, a.res_id, a.n * 4);
         memcpy(seg(PackLayout::RES_H_PTR) + 4ull * d.first_res, a.res_h_ptr, a.n_res * 4);
         memcpy(seg(PackLayout::RES_CB) + 4ull * d.first_res, a.res_cb, a.n_res * 4); memcpy(seg(PackLayout::RES_SG) + 4ull * d.first_res, a.res_sg, a.n_res * 4);
@@ -866,7 +866,7 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
     auto at = [&](int k) { return dev + lay.off[k]; };
     PackArrays &pa = sl.pa;
     pa.n = (uint32_t)pk.n; pa.n_res = (uint32_t)pk.n_res; pa.n_h = (uint32_t)pk.n_h; pa.K = (uint32_t)K;
-    pa.desc = (PackDesc *)at(PackLayout::DESC); pa.model = (uint16_t *)at(PackLayout::MODEL); pa.res_id = (uint32_t *)at(PackLayout::RES_ID);
+    pa.desc = (PackDesc *)at(PackLayout::DESC); pa.model = (uint32_t *)at(PackLayout::MODEL); pa.res_id = (uint32_t *)at(PackLayout::RES_ID);
     pa.res_h_ptr = (uint32_t *)at(PackLayout::RES_H_PTR); pa.res_cb = (uint32_t *)at(PackLayout::RES_CB); pa.res_sg = (uint32_t *)at(PackLayout::RES_SG);
     pa.res_h_idx = (uint32_t *)at(PackLayout::RES_H_IDX); pa.n_models = (uint32_t *)at(PackLayout::N_MODELS); pa.status = (uint32_t *)at(PackLayout::STATUS);
     pa.count = (unsigned long long *)at(PackLayout::COUNT); pa.offset = (unsigned long long *)at(PackLayout::OFFSET); pa.cursor = (unsigned long long *)at(PackLayout::CURSOR);
@@ -876,7 +876,7 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
     d.n = pa.n; d.n_res = pa.n_res; d.per_model = 1u;
     d.x = (const double *)at(PackLayout::X); d.y = (const double *)at(PackLayout::Y); d.z = (const double *)at(PackLayout::Z);
     d.attr = (const uint32_t *)at(PackLayout::ATTR); d.res_ord = (const uint32_t *)at(PackLayout::RES_ORD);
-    d.chain_rank = (const uint16_t *)at(PackLayout::CHAIN); d.model = pa.model;
+    d.chain_rank = (const uint32_t *)at(PackLayout::CHAIN); d.model = pa.model;
     d.res_id = pa.res_id; d.res_h_ptr = pa.res_h_ptr; d.res_h_idx = pa.res_h_idx; d.res_cb = pa.res_cb; d.res_sg = pa.res_sg;
     sl.ordered = false;  // (ordered calls are never packed, see the plan)
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
@@ -1080,10 +1080,9 @@ extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const d
     // the grid machinery of the contact search, over the side-chain atoms only: everything else is kept out by the attribute bit that
     // keeps hydrogens out of the contact grid
     std::vector<uint32_t> attr(n), zero32(n, 0);
-    std::vector<uint16_t> zero16(n, 0);
     for (uint64_t i = 0; i < n; i++) attr[i] = sidechain[i] ? (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR) : ARP_ATTR_H;
     arp_atoms a{};
-    a.n = n; a.x = x; a.y = y; a.z = z; a.attr = attr.data(); a.res_ord = zero32.data(); a.chain_rank = zero16.data(); a.model = zero16.data();
+    a.n = n; a.x = x; a.y = y; a.z = z; a.attr = attr.data(); a.res_ord = zero32.data(); a.chain_rank = zero32.data(); a.model = zero32.data();
     a.n_res = 0; a.location = ARP_MEM_HOST;
     arp_params prm;
     arp_default_params(&prm);

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = min(i0 + (uint32_t)u * stride, last);
-            at[u] = in.attr[i]; md[u] = (uint32_t)in.model[i];
+            at[u] = in.attr[i]; md[u] = in.model[i];
             p[u][0] = in.x[i]; p[u][1] = in.y[i]; p[u][2] = in.z[i];
         }
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
                 acc.mn[k] = use ? fmin(acc.mn[k], p[u][k]) : acc.mn[k];
                 acc.mx[k] = use ? fmax(acc.mx[k], p[u][k]) : acc.mx[k];
             }
-            acc.models = use ? max(acc.models, md[u] + 1u) : acc.models;
+            acc.models = use ? max(acc.models, min(md[u], 0xFFFFFFFEu) + 1u) : acc.models;
             acc.bad |= use ? (0x100u << (at[u] & ARP_ATTR_ELEM_MASK)) : 0u;  // bits 8..23: element classes present in the grid
             acc.bad |= (use & ((at[u] & (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR)) != (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR))) ? (1u << 24) : 0u;  // bit 24: an atom outside L or R
         }
@@ -418,7 +418,7 @@ DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so
     Fat f;
     f.x = x; f.y = y; f.z = z;
     f.pw = make_pair_word(attr, has_h); f.res_ord = in.res_ord[i];
-    f.crm = (uint32_t)in.chain_rank[i] | ((uint32_t)in.model[i] << 16); f.orig = i; f.cell = c;
+    f.crm = in.chain_rank[i]; f.orig = i; f.cell = c;
     f.attr = attr | (has_h ? kAttrResHasH : 0u);
     so.fat[d] = f;
 }
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void k_place(DevAtoms in, GridParams *gp, cons
         Fat f;
         f.x = x[u]; f.y = y[u]; f.z = z[u];
         f.pw = make_pair_word(attr, has_h); f.res_ord = ro[u];
-        f.crm = cr[u] | (md[u] << 16); f.orig = i; f.cell = c[u];
+        f.crm = cr[u]; f.orig = i; f.cell = c[u];
         f.attr = attr | (has_h ? kAttrResHasH : 0u);
         so.fat[slot] = f;
     }

@@ -71,7 +71,7 @@ struct arp_structure {
     arp::StrCol<8> name, resn /* conformer */, res_resn /* residue */, chain;
     arp::StrCol<4> altloc, icode, elem;
     std::vector<uint32_t> res_ord, res_id, base_attr, attr;
-    std::vector<uint16_t> chain_rank, model;
+    std::vector<uint32_t> chain_rank, model;
     std::vector<uint32_t> atom_chain;  // index into chains
     std::vector<arp::ChainInfo> chains;
     std::vector<arp::ResidueInfo> residues;

@@ -69,8 +69,10 @@ struct LdsParams {        // block-shared copy of the decision bounds (6.3 KB) +
 // At most one orientation can hold.  Hydrogens never reach here (they are not in the grid).  Written without branches:
 // the exact phase is instruction-issue bound and every divergent branch costs a handful of scalar exec-mask instructions.
 DEVFN int orient(const Fat &a, const Fat &b) {
-    const bool same_model = (a.crm >> 16) == (b.crm >> 16);             // :96-98
-    const uint32_t ca = a.crm & 0xFFFFu, cb = b.crm & 0xFFFFu;
+    // (:96-98, the same-model test, is the grid's: every model owns its own slab of cells + an empty separator layer, so a slot window never
+    // holds an atom of another model -- the chain rank has all 32 bits of crm)
+    const bool same_model = true;
+    const uint32_t ca = a.crm, cb = b.crm;
     const bool aL = a.pw & kPwLigand, aR = a.pw & kPwReceptor, bL = b.pw & kPwLigand, bR = b.pw & kPwReceptor;
     // same chain (:108,:113): (e2 > 1) && (e1 < e2 - 1)  <=>  e1 + 1 < e2   (ordinals are far below 2^32 - 1)
     const bool ab_chain = a.res_ord + 1u < b.res_ord, ba_chain = b.res_ord + 1u < a.res_ord;
@@ -85,7 +87,7 @@ DEVFN int orient(const Fat &a, const Fat &b) {
 // candidate iff the ordinals differ by >= 2 (:113), a cross-chain pair of one model always (:124-129), and in both cases the
 // ligand is the atom with the smaller (chain rank, ordinal) key.
 DEVFN int orient_all_both(const Fat &a, const Fat &b) {
-    const bool same_model = ((a.crm ^ b.crm) >> 16) == 0u, same_mc = a.crm == b.crm;
+    const bool same_model = true, same_mc = a.crm == b.crm;  // (the model: see orient)
     const bool gap = (b.res_ord - a.res_ord + 1u) > 2u;                  // |ordinal difference| >= 2
     const bool valid = same_model & (!same_mc | gap);
     const unsigned long long ka = ((unsigned long long)a.crm << 32) | a.res_ord, kb = ((unsigned long long)b.crm << 32) | b.res_ord;

@@ -233,8 +233,8 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
         m_ok = lm_lt_u32_sv(2u, d1) | lm_ne_u32((uint32_t)(ka >> 32), (uint32_t)(kb >> 32));  // another chain: always (:124-129); models never meet in the grid
         m_swap = lm_lt_u64(kb, ka);
     } else {  // chain groups: orient() of kernels.hip on lane masks (every comparison lands in a scalar register pair)
-        const uint32_t ca = (uint32_t)(ka >> 32) & 0xFFFFu, cb = (uint32_t)(kb >> 32) & 0xFFFFu;
-        const lmask same_model = ~lm_lt_u32_sv(0xFFFFu, (uint32_t)(ka >> 32) ^ (uint32_t)(kb >> 32));       // :96-98
+        const uint32_t ca = (uint32_t)(ka >> 32), cb = (uint32_t)(kb >> 32);
+        const lmask same_model = ~0ull;  // :96-98 is the grid's: a slot window never holds an atom of another model (arp_internal.h Fat::crm)
         const lmask same_chain = ~lm_ne_u32(ca, cb);
         const lmask ab_chain = lm_lt_u32_vv((uint32_t)ka + 1u, (uint32_t)kb), ba_chain = lm_lt_u32_vv((uint32_t)kb + 1u, (uint32_t)ka);  // :108,:113
         const uint32_t lr = pa & pb;                                                                            // bit 24: both ligand, bit 25: both receptor

@@ -489,10 +489,11 @@ static arp_status build(const std::vector<Record> &recs, int hierarchy, bool dro
     std::set<std::string> ids;
     for (const ChainInfo &c : chains) ids.insert(c.id);
     s->chain_ids.assign(ids.begin(), ids.end());  // std::string ordering == Rust &str ordering (byte-wise)
-    if (s->chain_ids.size() > 65535 || (chains.empty() ? 0u : chains.back().model_idx) > 65535) { set_error("too many chains / models"); return ARP_ERR_BAD_INPUT; }
-    std::unordered_map<std::string, uint16_t> rank;
-    for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
-    std::vector<uint16_t> rank_of_chain(chains.size());
+    // (API v2: chain ranks and model ordinals are 32-bit -- the reference keys on the chain id STRING, complex.rs:19-21, and has no chain limit)
+    if (s->chain_ids.size() >= 0xFFFFFFF0ull || chains.size() >= 0xFFFFFFF0ull) { set_error("too many chains / models"); return ARP_ERR_BAD_INPUT; }
+    std::unordered_map<std::string, uint32_t> rank;
+    for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint32_t)k;
+    std::vector<uint32_t> rank_of_chain(chains.size());
     for (size_t c = 0; c < chains.size(); c++) rank_of_chain[c] = rank[chains[c].id];
     for (size_t k = 0; k < n; k++) {
         const Record &r = recs[keep_idx[k]];
@@ -505,7 +506,7 @@ static arp_status build(const std::vector<Record> &recs, int hierarchy, bool dro
         s->res_id[k] = new_id[rec_res[keep_idx[k]]];
         s->atom_chain[k] = br.chain;
         s->chain_rank[k] = rank_of_chain[br.chain];
-        s->model[k] = (uint16_t)chains[br.chain].model_idx;
+        s->model[k] = (uint32_t)chains[br.chain].model_idx;
         int cls = element_class(r.elem);
         if (cls < 0) { set_error("atom %d (%s %s): element '%s' has no radii in this build", r.serial, r.resn, r.name, r.elem); return ARP_ERR_BAD_INPUT; }
         s->base_attr[k] = atom_attr(r.resn, br.name.c_str(), r.name, r.elem, cls);

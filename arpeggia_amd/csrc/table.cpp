@@ -113,7 +113,7 @@ struct PlaneEntry {
     Plane plane;
     bool has_ord = false; uint32_t ord = 0;   // res2idx[(model, chain, resi, icode, altloc, resn)]
     uint32_t res = 0, alt_k = 0;              // the residue (and which of its conformer altlocs) the plane was last written from
-    uint16_t chain_rank = 0; bool in_l = false, in_r = false;
+    uint32_t chain_rank = 0; bool in_l = false, in_r = false;
 };
 // (model serial, chain id, resi, icode, altloc, resn) with the names packed into integers (ids are <= 7 / 3 characters, the
 // widths of the string columns): hashing and comparing keys costs no allocation.
@@ -237,7 +237,7 @@ static void fit_planes_host(const arp_structure &s, const std::vector<uint8_t> &
 }
 
 // should_compare_residues (complex.rs:94-131) on prepared keys
-struct ResKey { int32_t model_serial; uint16_t chain_rank; uint32_t ord; bool in_l, in_r; };
+struct ResKey { int32_t model_serial; uint32_t chain_rank; uint32_t ord; bool in_l, in_r; };
 static bool compare_residues(const ResKey &a, const ResKey &b, bool symmetric) {
     if (a.model_serial != b.model_serial) return false;
     if (!((a.in_l && b.in_r) || (b.in_l && a.in_r))) return false;
@@ -291,7 +291,7 @@ namespace {
 struct Entity {  // structs.rs:55-70; fixed NUL-padded names (the widths of the table's string columns): rows stay POD
     char chain[8], resn[8], atomn[8], insertion[4], altloc[4];
     int32_t resi = 0, atomi = 0, atom = -1;
-    uint16_t chain_rank = 0;
+    uint32_t chain_rank = 0;
     int64_t sc_plane = -1;
 };
 struct Row {
@@ -512,7 +512,7 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
                      {s->attr.data(), n * 4, (void **)&d.attr}, {s->res_ord.data(), n * 4, (void **)&d.res_ord}, {s->res_id.data(), n * 4, (void **)&d.res_id},
                      {s->res_h_ptr.data(), (nr + 1) * 4, (void **)&d.res_h_ptr}, {s->res_h_idx.data(), nh * 4, (void **)&d.res_h_idx},
                      {s->res_cb.data(), nr * 4, (void **)&d.res_cb}, {s->res_sg.data(), nr * 4, (void **)&d.res_sg},
-                     {s->chain_rank.data(), n * 2, (void **)&d.chain_rank}, {s->model.data(), n * 2, (void **)&d.model},
+                     {s->chain_rank.data(), n * 4, (void **)&d.chain_rank}, {s->model.data(), n * 4, (void **)&d.model},
                      {c->plane_bits.data(), n, (void **)&d.plane_bits}, {c->res_atom_ptr.data(), (nr + 1) * 4, (void **)&d.res_atom_ptr},
                      {c->res_atom_idx.data(), c->res_atom_idx.size() * 4, (void **)&d.res_atom_idx}, {c->atom_sc_src.data(), n * 4, (void **)&d.atom_sc_src},
                      {c->atom_keys.data(), n * sizeof(EntKey), (void **)&d.ent_key}, {c->model_rank.data(), nm * 4, (void **)&d.model_rank},
@@ -589,8 +589,8 @@ arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *g
     // with thousands of chains this bookkeeping costs more than the GPU pair pass.
     if (!c->have_rings_dev || c->rings_groups != groups) {
         std::vector<char> chain_l(s->chain_ids.size(), 0), chain_r(s->chain_ids.size(), 0);
-        std::unordered_map<std::string, uint16_t> rank;
-        for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
+        std::unordered_map<std::string, uint32_t> rank;
+        for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint32_t)k;
         {
             std::vector<std::string> L, R;
             if ((st = parse_groups(s->chain_ids, groups, &L, &R)) != ARP_OK) return st;

@@ -31,7 +31,7 @@ struct DevStructure {
     uint64_t n = 0, n_res = 0, n_h = 0;
     double *x = nullptr, *y = nullptr, *z = nullptr;
     uint32_t *attr = nullptr, *res_ord = nullptr, *res_id = nullptr, *res_h_ptr = nullptr, *res_h_idx = nullptr, *res_cb = nullptr, *res_sg = nullptr;
-    uint16_t *chain_rank = nullptr, *model = nullptr;
+    uint32_t *chain_rank = nullptr, *model = nullptr;
     uint8_t *plane_bits = nullptr;       // per atom: 1 = ring-plane atom (residues.rs:163-186), 2 = sc-plane atom (residues.rs:188-268)
     uint32_t *res_atom_ptr = nullptr, *res_atom_idx = nullptr;   // residue -> atoms in hierarchy order
     uint32_t *atom_sc_src = nullptr;     // per atom: residue whose sc plane applies, or ARP_NONE

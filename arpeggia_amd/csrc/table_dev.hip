@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void k_ring_atom(uint32_t n_rings, const RingEn
                     const double q[3] = {f.x, f.y, f.z};
                     const double dx = q[0] - pl.c[0], dy = q[1] - pl.c[1], dz = q[2] - pl.c[2];
                     if (!(dx * dx + dy * dy + dz * dz <= r2)) continue;  // rstar: inclusive (complex.rs:310)
-                    const ResKeyD yk{ring.model_serial, f.crm & 0xFFFFu, f.res_ord, (f.attr & ARP_ATTR_LIGAND) != 0u, (f.attr & ARP_ATTR_RECEPTOR) != 0u};
+                    const ResKeyD yk{ring.model_serial, f.crm, f.res_ord, (f.attr & ARP_ATTR_LIGAND) != 0u, (f.attr & ARP_ATTR_RECEPTOR) != 0u};
                     if (!compare_residues_d(rk, yk, false)) continue;
                     const double dist = point_dist_d(pl, q), theta = point_angle_d(pl, q);
                     if (theta <= 30.0 && dist <= 4.5) append_row(rows, n_rows, cap, n_atoms + e, f.orig, dist, ARP_CationPi);
@@ -238,10 +238,10 @@ __global__ __launch_bounds__(256) void k_expand_rows(const arp_pair *pairs, uint
 // chains are equal, and a rank inside the chain needs bits(largest chain) instead of bits(all entities) -- which is what lets all ten keys
 // of a row share one 64-bit radix key (a million entities in 1500 chains: 48 bits instead of 68).
 __device__ inline uint32_t bias(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
-__device__ inline uint32_t ent_chain(uint32_t e, uint32_t n_atoms, const uint16_t *chain_rank, const RingEnt *rings) {
+__device__ inline uint32_t ent_chain(uint32_t e, uint32_t n_atoms, const uint32_t *chain_rank, const RingEnt *rings) {
     return e < n_atoms ? (uint32_t)chain_rank[e] : rings[e - n_atoms].chain_rank;
 }
-__global__ __launch_bounds__(256) void k_ent_key(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint16_t *chain_rank,
+__global__ __launch_bounds__(256) void k_ent_key(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint32_t *chain_rank,
                                                  const RingEnt *rings, int pass, const uint32_t *ids, unsigned long long *key) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_ent) return;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_ent_key(uint32_t n_ent, const EntKey *a
     key[p] = pass == 0 ? (unsigned long long)bias(k.atomi) : (((unsigned long long)bias(k.resi) << 32) | k.altloc);
 }
 // entities sorted by (chain, resi, altloc, atomi): flag = the key differs from the predecessor's
-__global__ __launch_bounds__(256) void k_ent_flags(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint16_t *chain_rank,
+__global__ __launch_bounds__(256) void k_ent_flags(uint32_t n_ent, const EntKey *atom_keys, uint32_t n_atoms, const EntKey *ring_keys, const uint32_t *chain_rank,
                                                    const RingEnt *rings, const uint32_t *ids, uint32_t *flag) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_ent) return;
@@ -264,14 +264,14 @@ __global__ __launch_bounds__(256) void k_ent_flags(uint32_t n_ent, const EntKey 
     flag[p] = f;
 }
 // scan = dense rank over all entities; base[chain] = the rank its first entity got
-__global__ __launch_bounds__(256) void k_ent_base(uint32_t n_ent, uint32_t n_atoms, const uint16_t *chain_rank, const RingEnt *rings, const uint32_t *ids, const uint32_t *scan,
+__global__ __launch_bounds__(256) void k_ent_base(uint32_t n_ent, uint32_t n_atoms, const uint32_t *chain_rank, const RingEnt *rings, const uint32_t *ids, const uint32_t *scan,
                                                   uint32_t *base) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_ent) return;
     const uint32_t c = ent_chain(ids[p], n_atoms, chain_rank, rings);
     if (p == 0 || ent_chain(ids[p - 1], n_atoms, chain_rank, rings) != c) base[c] = scan[p];
 }
-__global__ __launch_bounds__(256) void k_ent_rank(uint32_t n_ent, uint32_t n_atoms, const uint16_t *chain_rank, const RingEnt *rings, const uint32_t *ids, const uint32_t *scan,
+__global__ __launch_bounds__(256) void k_ent_rank(uint32_t n_ent, uint32_t n_atoms, const uint32_t *chain_rank, const RingEnt *rings, const uint32_t *ids, const uint32_t *scan,
                                                   const uint32_t *base, uint32_t *rank, uint32_t *max_rank) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t r = 0;
@@ -294,7 +294,7 @@ struct SortTables {
     uint32_t rank_bits, chain_bits;   // widths of an entity rank / a chain rank in the merged keys
 };
 __global__ __launch_bounds__(256) void k_row_key(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, int pass, uint32_t n_atoms, const EntKey *atom_keys,
-                                                 const EntKey *ring_keys, const uint32_t *ent_rank, const uint16_t *chain_rank, const uint16_t *model, const uint32_t *model_rank,
+                                                 const EntKey *ring_keys, const uint32_t *ent_rank, const uint32_t *chain_rank, const uint32_t *model, const uint32_t *model_rank,
                                                  const RingEnt *rings, SortTables tb, unsigned long long *key) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_rows) return;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_row_key(uint32_t n_rows, const uint4 *r
 // and the host sorts again the long way.
 constexpr uint32_t kTieRun = 64;
 __global__ __launch_bounds__(256) void k_tie_fix(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, const unsigned long long *sorted_key, uint32_t n_atoms,
-                                                 const EntKey *atom_keys, const EntKey *ring_keys, const uint32_t *ent_rank, const uint16_t *chain_rank, const uint16_t *model,
+                                                 const EntKey *atom_keys, const EntKey *ring_keys, const uint32_t *ent_rank, const uint32_t *chain_rank, const uint32_t *model,
                                                  const uint32_t *model_rank, const RingEnt *rings, uint32_t *perm_out, uint32_t *overflow) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_rows) return;
@@ -485,7 +485,7 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
     // entity ranks: sort the entities by (chain, resi, altloc, atomi), least significant key first; rank = number of key changes since the
     // chain's first entity
     if (derive) {
-        const uint16_t *chain = (const uint16_t *)ds.chain_rank;
+        const uint32_t *chain = (const uint32_t *)ds.chain_rank;
         hipLaunchKernelGGL(k_iota, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, eid0);
         hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, chain,
                            (const RingEnt *)d_rings, 0, (const uint32_t *)nullptr, ek0);
@@ -498,12 +498,16 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         hipLaunchKernelGGL(k_ent_key, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, chain,
                            (const RingEnt *)d_rings, 2, (const uint32_t *)eid0, ek0);
         tmp = cub_sort_ent;
-        TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tmp, (const unsigned long long *)ek0, ek1, (const uint32_t *)eid0, eid1, (int)n_ent, 0, 16, st));
+        {   // (the chain pass: as many key bits as the structure's chain count needs -- 32-bit chain ranks since API v2)
+            int chain_key_bits = 1;
+            while (chain_key_bits < 32 && (1ull << chain_key_bits) < std::max<uint64_t>(ds.n_chains, 1)) chain_key_bits++;
+            TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tmp, (const unsigned long long *)ek0, ek1, (const uint32_t *)eid0, eid1, (int)n_ent, 0, chain_key_bits, st));
+        }
         hipLaunchKernelGGL(k_ent_flags, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (const EntKey *)ds.ent_key, (uint32_t)n, (const EntKey *)d_ring_keys, chain,
                            (const RingEnt *)d_rings, (const uint32_t *)eid1, eflag);
         tmp = cub_scan;
         TRY_HIP(hipcub::DeviceScan::InclusiveSum(cub_tmp, tmp, (const uint32_t *)eflag, eid0, (int)n_ent, st));
-        uint32_t *chain_base = reinterpret_cast<uint32_t *>(ek0);  // (the sort keys are done with: 65536 words of them hold the per-chain bases)
+        uint32_t *chain_base = reinterpret_cast<uint32_t *>(ek0);  // (the sort keys are done with: their first n_chains words hold the per-chain bases; n_chains <= n_ent)
         hipLaunchKernelGGL(k_ent_base, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (uint32_t)n, chain, (const RingEnt *)d_rings, (const uint32_t *)eid1, (const uint32_t *)eid0,
                            chain_base);
         hipLaunchKernelGGL(k_ent_rank, grid(n_ent, 256), dim3(256), 0, st, (uint32_t)n_ent, (uint32_t)n, chain, (const RingEnt *)d_rings, (const uint32_t *)eid1, (const uint32_t *)eid0,
@@ -582,7 +586,7 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         for (int q = 0; q < n_pass; q++) {
             const int pass = plan[q];
             hipLaunchKernelGGL(k_row_key, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, pass, (uint32_t)n, (const EntKey *)ds.ent_key,
-                               (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint16_t *)ds.chain_rank, (const uint16_t *)ds.model, (const uint32_t *)ds.model_rank,
+                               (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint32_t *)ds.chain_rank, (const uint32_t *)ds.model, (const uint32_t *)ds.model_rank,
                                (const RingEnt *)d_rings, tb, rk0);
             size_t tmp = cub_sort_rows;
             TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp2, tmp, (const unsigned long long *)rk0, rk1, (const uint32_t *)pin_, pout, (int)n_rows, 0, end_bit[q], st));
@@ -591,7 +595,7 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         if (!long_way) {
             const bool one_key = plan[n_pass - 1] == 6 && n_pass == 1;  // rk1 then holds every row's ten keys, in sorted order
             hipLaunchKernelGGL(k_tie_fix, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, one_key ? (const unsigned long long *)rk1 : nullptr,
-                               (uint32_t)n, (const EntKey *)ds.ent_key, (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint16_t *)ds.chain_rank, (const uint16_t *)ds.model,
+                               (uint32_t)n, (const EntKey *)ds.ent_key, (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint32_t *)ds.chain_rank, (const uint32_t *)ds.model,
                                (const uint32_t *)ds.model_rank, (const RingEnt *)d_rings, pout, counters + 1);
             std::swap(pin_, pout);
         }

@@ -85,14 +85,14 @@ def pack_soas(soas):
         n, nr = len(s["x"]), len(s["res_cb"])
         for k in ("x", "y", "z", "attr", "res_ord", "chain_rank"):
             cat[k].append(s[k])
-        cat["model"].append((s["model"].astype(np.uint32) + m0).astype(np.uint16))
+        cat["model"].append(s["model"].astype(np.uint32) + np.uint32(m0))
         cat["res_id"].append(s["res_id"] + np.uint32(r0))
         cat["res_h_ptr"].append(s["res_h_ptr"][:-1] + np.uint32(h0))
         for k in ("res_cb", "res_sg"):
             cat[k].append(np.where(s[k] == none, none, s[k] + np.uint32(a0)))
         cat["res_h_idx"].append(s["res_h_idx"] + np.uint32(a0))
         a0 += n; r0 += nr; h0 += int(s["res_h_ptr"][-1]); m0 += int(s["model"].max(initial=0)) + 1
-    assert m0 < 65536, "a pack holds at most 65535 models"
+    assert m0 < 65536, "a pack holds at most 65535 models (the per-model boxes of the workspace)"
     out = {k: np.concatenate(v) if v else np.zeros(0) for k, v in cat.items()}
     out["res_h_ptr"] = np.concatenate([out["res_h_ptr"], np.asarray([h0], dtype=np.uint32)]).astype(np.uint32)
     return out

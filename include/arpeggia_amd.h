@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ARP_API_VERSION 1
+#define ARP_API_VERSION 2   /* v2 (round 4): arp_atoms.chain_rank and arp_atoms.model are 32-bit (v1: uint16_t, at most 65 535 chains / models) */
 
 typedef int32_t arp_status;
 enum {
@@ -70,8 +70,10 @@ typedef struct arp_atoms {
     const double *x, *y, *z;     /* f64 coordinates (pdbtbx Atom::pos)                                        */
     const uint32_t *attr;        /* ARP_ATTR_* bits                                                           */
     const uint32_t *res_ord;     /* positional index of the residue in its chain (complex.rs:411-440)         */
-    const uint16_t *chain_rank;  /* rank of the chain id under byte-wise string order (complex.rs:129)        */
-    const uint16_t *model;       /* model ordinal (complex.rs:96-98 same-model test)                          */
+    const uint32_t *chain_rank;  /* rank of the chain id under byte-wise string order (complex.rs:129); the reference keys on the id
+                                  * STRING (complex.rs:19-21): any number of chains                                     */
+    const uint32_t *model;       /* model ordinal 0, 1, 2, ... (complex.rs:96-98 same-model test); dense: every model owns a
+                                  * slab of the cell grid, the largest ordinal is bounded by the grid (~4 per atom)             */
     /* tables for the rare data-dependent rules; may be NULL when n_res == 0 (then no H probes, no disulfides) */
     const uint32_t *res_id;      /* per atom: global residue ordinal                                          */
     uint64_t n_res;

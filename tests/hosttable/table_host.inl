@@ -30,8 +30,8 @@ static arp_status get_contacts_host(arp_context *ctx, arp_structure *s, const ch
         build_planes(*s, false, has_sc, &fit_sc, &scp, &sc_idx, &sc_first);
     }
     const bool direct = !sc_first.empty() || s->residues.empty();
-    std::unordered_map<std::string, uint16_t> rank;
-    for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint16_t)k;
+    std::unordered_map<std::string, uint32_t> rank;
+    for (size_t k = 0; k < s->chain_ids.size(); k++) rank[s->chain_ids[k]] = (uint32_t)k;
     std::vector<char> chain_l(s->chain_ids.size(), 0), chain_r(s->chain_ids.size(), 0);
     for (size_t i = 0; i < s->n; i++) { chain_l[s->chain_rank[i]] = (s->attr[i] & ARP_ATTR_LIGAND) != 0; chain_r[s->chain_rank[i]] = (s->attr[i] & ARP_ATTR_RECEPTOR) != 0; }
     {   // chains without atoms still belong to the sets
@@ -204,7 +204,7 @@ static arp_status get_contacts_host(arp_context *ctx, arp_structure *s, const ch
     // Sort keys as plain integers, compared in place (no indirection into the rows): names as big-endian words, so that an
     // unsigned compare is the byte-wise string order polars uses.
     struct SortKey {
-        uint32_t model; uint16_t from_chain, to_chain;
+        uint32_t model; uint32_t from_chain, to_chain;
         int32_t from_resi; uint32_t from_altloc; int32_t from_atomi, to_resi; uint32_t to_altloc; int32_t to_atomi, interaction;
         uint32_t from_ins, to_ins; double distance; uint32_t idx;
     };

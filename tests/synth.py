@@ -192,6 +192,59 @@ def gen_s1(n_atoms: int, seed: int = 0xA11CE5EED00 + 3, spacing: float = 30.0, c
 
 
 # ------------------------------------------------------------------------------------------------ stress
+def gen_many_chains(n_chains: int = 70000, seed: int = 31, spacing: float = 5.8, max_atoms: int = 6) -> dict:
+    """One residue per chain, more chains than a 16-bit rank holds (arpeggia_amd.h API v2; the reference keys on the chain id string,
+    complex.rs:19-21): residues of 1ubq (waters excluded) at random orientations on a jittered cubic lattice, every one with a chain id of
+    its own -- ids that do NOT sort in file order, so that rank and file order differ.  Hierarchy-free records (the builders derive it)."""
+    rng = np.random.default_rng(seed)
+    tmpl = read_pdb_records(DATA / "1ubq.pdb")
+    keep = tmpl["resn"] != b"HOH"
+    tmpl = {k: v[keep] for k, v in tmpl.items()}
+    resi = tmpl["resi"]
+    starts = np.flatnonzero(np.concatenate([[True], resi[1:] != resi[:-1]]))
+    ends = np.concatenate([starts[1:], [len(resi)]])
+    small = (ends - starts) <= max_atoms  # (the oracle compares chain id strings per pair: keep the pair count of the test in check)
+    phe = int(np.flatnonzero(tmpl["resn"][starts] == b"PHE")[0])  # ... plus ONE aromatic residue: without any ring the table path errors
+    small[phe] = True                                              # like the reference panics (complex.rs:50,480-482)
+    phe_t = int(small[:phe].sum())
+    starts, ends = starts[small], ends[small]
+    n_t = len(starts)
+    side = int(np.ceil(n_chains ** (1.0 / 3.0)))
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3)[:n_chains]
+    centre = g * spacing + rng.uniform(-0.8, 0.8, size=(n_chains, 3))
+    which = rng.integers(0, n_t, n_chains)
+    which[which == phe_t] = (phe_t + 1) % n_t
+    which[0] = phe_t  # (chain 0 is the one phenylalanine)
+    rots = _random_rotations(rng, n_chains)
+    cols = {k: [] for k in ("x", "y", "z", "occupancy", "serial", "resi", "name", "resn", "chain", "altloc", "icode", "element", "model_serial")}
+    ids = rng.permutation(n_chains)  # chain c is called K<ids[c]>: byte-wise order != file order
+    xyz_all, meta = [], []
+    for t in range(n_t):  # vectorised per template residue
+        sel = np.flatnonzero(which == t)
+        if not len(sel):
+            continue
+        sl = slice(starts[t], ends[t])
+        base = np.stack([tmpl["x"][sl], tmpl["y"][sl], tmpl["z"][sl]], 1)
+        base = base - base.mean(0)
+        pos = np.einsum("cij,aj->cai", rots[sel], base) + centre[sel][:, None, :]
+        xyz_all.append((sel, pos, sl))
+    order = []  # file order = chain order, atoms of a residue together
+    per_chain = {}
+    for sel, pos, sl in xyz_all:
+        for k, c in enumerate(sel):
+            per_chain[int(c)] = (pos[k], sl)
+    serial = 1
+    for c in range(n_chains):
+        pos, sl = per_chain[c]
+        na = pos.shape[0]
+        cols["x"].extend(np.round(pos[:, 0], 3)); cols["y"].extend(np.round(pos[:, 1], 3)); cols["z"].extend(np.round(pos[:, 2], 3))
+        cols["occupancy"].extend([1.0] * na); cols["serial"].extend(range(serial, serial + na)); serial += na
+        cols["resi"].extend([1] * na); cols["name"].extend(tmpl["name"][sl]); cols["resn"].extend(tmpl["resn"][sl])
+        cols["chain"].extend([b"K%06d" % int(ids[c])] * na); cols["altloc"].extend([b""] * na); cols["icode"].extend([b""] * na)
+        cols["element"].extend(tmpl["element"][sl]); cols["model_serial"].extend([0] * na)
+    return _finish(cols)
+
+
 def gen_stress(n_res: int = 400, seed: int = 7, box: float = 28.0, hydrogens: bool = True, n_models: int = 1, n_chains: int = 4,
                altlocs: bool = False) -> dict:
     """Whole residues of 6bft at random poses in a small box: overlaps give clashes / covalent-band pairs, CYS pairs give

@@ -144,6 +144,44 @@ def test_radii_with_vdw_below_cov_agree_between_the_emitters(ctx):
     assert not (emit["kind"] & (1 << ob.INTERACTIONS.index("VanDerWaalsContact"))).any()  # the vdW band is empty: it lies inside the covalent one
 
 
+def test_more_than_65535_chains(ctx):
+    """API v2: chain ranks are 32-bit.  70 000 one-residue chains whose ids do not sort in file order (the reference keys on the chain id
+    string and orders `cx > cy` byte-wise, complex.rs:124-129): the pair list against the oracle with both emitters and contacts only, the
+    chain-group forms that need ranks on both sides, and the device table's chain columns / sort with 17-bit chain keys."""
+    rec = synth.gen_many_chains(70000)
+    assert len(np.unique(rec["chain"])) == 70000
+    prod = aa.Structure.from_records(rec)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+    soa = prod.soa("/")
+    assert soa["chain_rank"].dtype == np.uint32 and int(soa["chain_rank"].max()) == 69999
+    got, want = run_both(ctx, prod, orc)
+    assert len(want) > 500_000
+    assert_pairs_equal(got, want, "70 000 chains")
+    only = ctx.atomic_contacts(prod.view("/"), aa.default_params(contacts_only=True))
+    assert_pairs_equal(only, want[want["kind"] != 0], "70 000 chains, contacts only")
+    # six chains against all the others (the L/R bits, the cross-chain rule with ranks beyond 2^16).  Expected = the all-against-all pairs with
+    # exactly one atom in the six chains, that atom first (no hydrogens here: a pair's kinds do not depend on its orientation) -- a second
+    # pass of the oracle, which compares chain id strings per pair, would take another half minute.
+    some = np.unique(rec["chain"])[::11000][:6]
+    groups = ",".join(c.decode() for c in some) + "/"
+    in_l = np.isin(rec["chain"], some)
+    li, lj = in_l[want["i"]], in_l[want["j"]]
+    pick = li != lj
+    want_g = want[pick].copy()
+    flip = lj[pick]
+    want_g["i"], want_g["j"] = np.where(flip, want["j"][pick], want["i"][pick]), np.where(flip, want["i"][pick], want["j"][pick])
+    assert len(want_g) > 100
+    for det in (False, True):
+        assert_pairs_equal(ctx.atomic_contacts(prod.view(groups), aa.default_params(deterministic=det)), want_g, f"{groups} det={det}")
+    # the table (the oracle's own table takes ten minutes on this many chains): one row per set bit of the oracle's pair kinds -- the
+    # residues are too small for ring rows -- with the chain columns in the reference's sort order (mod.rs:120-134: model, from_chain, to_chain)
+    cols = ctx.get_contacts(prod, "/", 0.1, 6.5)
+    n_rows = int(sum(bin(int(k)).count("1") for k in np.unique(want["kind"]) for _ in range(int((want["kind"] == k).sum()))))
+    assert len(cols["model"]) == n_rows > 100_000
+    key = np.char.add(cols["from_chain"].astype("S8"), cols["to_chain"].astype("S8"))
+    assert (key[1:] >= key[:-1]).all() and np.unique(cols["from_chain"])[-1] > b"K065536" and np.unique(cols["to_chain"])[-1] > b"K065536"  # (ranks beyond 16 bits in both columns)
+
+
 def test_cys_without_cb_is_an_error_like_the_reference_panic(ctx):
     # vdw.rs:55-58: cb1 = residue.atoms().find(CB).unwrap()
     rec = synth.gen_stress(n_res=60, seed=21, hydrogens=False)
@@ -239,7 +277,7 @@ def _both_from(rec):
 
 
 def test_empty_and_tiny_inputs(ctx):
-    zero = {k: np.zeros(0, dtype=d) for k, d in (("x", "f8"), ("y", "f8"), ("z", "f8"), ("attr", "u4"), ("res_ord", "u4"), ("chain_rank", "u2"), ("model", "u2"))}
+    zero = {k: np.zeros(0, dtype=d) for k, d in (("x", "f8"), ("y", "f8"), ("z", "f8"), ("attr", "u4"), ("res_ord", "u4"), ("chain_rank", "u4"), ("model", "u4"))}
     assert len(ctx.atomic_contacts(zero)) == 0
     prod, orc = _both_from(_mini([[1, 2, 3]]))
     got, want = run_both(ctx, prod, orc)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == declared
-    assert _lib.lib.arp_api_version() == 1
+    assert _lib.lib.arp_api_version() == 2
 
 
 def test_struct_layouts_match_header(c_consumer):
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(c_consumer):
     r = subprocess.run([c_consumer, "--abi"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     abi = json.loads(r.stdout)
-    assert abi["api_version"] == _lib.lib.arp_api_version() == 1
+    assert abi["api_version"] == _lib.lib.arp_api_version() == 2
     mirrors = {"arp_atoms": _lib.arp_atoms, "arp_params": _lib.arp_params, "arp_pair": _lib.arp_pair, "arp_pairs": _lib.arp_pairs, "arp_records": _lib.arp_records}
     assert set(abi["structs"]) == set(mirrors)
     for name, T in mirrors.items():
@@ -105,7 +105,7 @@ def _compare_structure(prod: aa.Structure, orc: ob.Structure, groups="/"):
         assert np.array_equal(got, want), name
     # chain rank == rank under byte-wise order
     ids = sorted(set(oa["chain"]))
-    assert np.array_equal(soa["chain_rank"], np.array([ids.index(c) for c in oa["chain"]], dtype=np.uint16))
+    assert np.array_equal(soa["chain_rank"], np.array([ids.index(c) for c in oa["chain"]], dtype=np.uint32))
     # element class radii
     prm = aa.default_params()
     import ctypes as C
