@@ -230,6 +230,7 @@ extern "C" arp_status arp_context_create(int32_t device, arp_context **out) try 
 
 static void free_staged(arp_context *ctx) {
     auto &s = ctx->st;
+    if (ctx->nodefer_x == (const double *)s.dev) { ctx->nodefer_x = nullptr; ctx->nodefer_n = 0; }  // (a memo must not outlive the buffer it names)
     if (s.dev) (void)hipFree(s.dev);
     if (s.pinned) (void)hipHostFree(s.pinned);
     s = arp_context::Staged{};
@@ -312,6 +313,9 @@ static arp_status stage_inputs(arp_context *ctx, const arp_atoms *a, DevAtoms *d
     }
     for (const Seg &g : seg) if (g.bytes) memcpy(s.pinned + g.off, g.src, g.bytes);
     HIP_TRY(hipMemcpyAsync(s.dev, s.pinned, total, hipMemcpyHostToDevice, ctx->stream));
+    // The deferred-pass memo identifies an input by (x pointer, n): for host inputs that pointer is THIS staging buffer, whatever structure it
+    // carries -- every host call of the same size would hit, and a stale hit costs a whole second pass.  Host inputs never use the memo.
+    ctx->nodefer_x = nullptr; ctx->nodefer_n = 0;
     auto at = [&](int k) -> const void * { return s.dev + seg[k].off; };
     d->x = (const double *)at(0); d->y = (const double *)at(1); d->z = (const double *)at(2);
     d->attr = (const uint32_t *)at(3); d->res_ord = (const uint32_t *)at(4);
@@ -338,6 +342,7 @@ constexpr arp_status kRetryDeferPass = -2;  // internal: the deferred pass was s
 static bool skip_deferred_pass(arp_context *ctx, const DevAtoms &d) { return d.x != nullptr && ctx->nodefer_x == d.x && ctx->nodefer_n == d.n; }
 // after the results of a single-pass (emit) call have been read into h_result
 static void note_deferred(arp_context *ctx, const DevAtoms &d, bool skipped) {
+    if (ctx->st.dev && d.x == (const double *)ctx->st.dev) return;  // host input staged by the context: no memo (stage_inputs)
     if (skipped) { if (ctx->h_result[1] & 128ull) { ctx->nodefer_x = nullptr; ctx->nodefer_n = 0; } return; }
     if (ctx->h_result[3] == 0ull && !(ctx->h_result[1] & ~1ull)) { ctx->nodefer_x = d.x; ctx->nodefer_n = d.n; }
     else if (ctx->nodefer_x == d.x) { ctx->nodefer_x = nullptr; ctx->nodefer_n = 0; }
@@ -628,14 +633,22 @@ std::mutex g_shared_mu;
 std::unordered_map<const void *, SharedBlock *> g_shared_views;
 std::vector<SharedBlock *> g_shared_pool;
 size_t g_shared_pool_bytes = 0;
-constexpr size_t kSharedPoolLimit = 6ull << 30;  // idle pinned memory kept for the next batch
+// idle pinned memory kept for the next batch / table: 2 GiB unless ARPEGGIA_AMD_HOST_POOL_MB says otherwise (0 = keep nothing)
+const size_t kSharedPoolLimit = [] {
+    const char *e = getenv("ARPEGGIA_AMD_HOST_POOL_MB");
+    const long long mb = e ? atoll(e) : 2048;
+    return (size_t)(mb < 0 ? 0 : mb) << 20;
+}();
 
 SharedBlock *shared_acquire(size_t bytes) {
     {
         std::lock_guard<std::mutex> lk(g_shared_mu);
         size_t best = g_shared_pool.size();
         for (size_t k = 0; k < g_shared_pool.size(); k++)
-            if (g_shared_pool[k]->cap >= bytes && (best == g_shared_pool.size() || g_shared_pool[k]->cap < g_shared_pool[best]->cap)) best = k;
+            // (the smallest pooled block that fits -- but not one more than twice the request + 1 MiB: a 1 KB table must not pin a multi-GB block
+            // for as long as one of its views lives)
+            if (g_shared_pool[k]->cap >= bytes && g_shared_pool[k]->cap <= 2 * bytes + (1u << 20) &&
+                (best == g_shared_pool.size() || g_shared_pool[k]->cap < g_shared_pool[best]->cap)) best = k;
         if (best != g_shared_pool.size()) {
             SharedBlock *b = g_shared_pool[best];
             g_shared_pool.erase(g_shared_pool.begin() + (long)best);

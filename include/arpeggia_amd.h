@@ -176,7 +176,8 @@ arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_pairs);
 arp_status arp_contacts_atomic_batch(arp_context *const *ctxs, int32_t n_ctx, const arp_atoms *const *atoms,
                                      int32_t n_structures, const arp_params *params, arp_pairs *outs);
 /* Pinned host blocks whose last pair list or table has been freed are kept for the next batch / table (pinning memory costs far more than
- * the copy it saves; at most 6 GiB stay pooled).  This returns the idle ones to the system; blocks still referenced are untouched.
+ * the copy it saves; at most 2 GiB stay pooled -- ARPEGGIA_AMD_HOST_POOL_MB in the environment sets another limit, 0 keeps nothing -- and a
+ * request only reuses a pooled block of at most twice its size).  This returns the idle ones to the system; blocks still referenced are untouched.
  * Returns the number of bytes released. */
 uint64_t arp_release_host_pool(void);
 

@@ -822,6 +822,38 @@ def _lines_close(got, want):
                 assert abs(float(x) - float(y)) <= tol, (a, b)
 
 
+def test_first_table_call_then_immediate_free_and_first_calls_from_several_threads():
+    """the first get_contacts call on a structure starts a job that fills the entity book while the device works; freeing the
+    structure right after that call (the table still alive: it owns its columns) and first calls on several structures from several threads
+    (each with its own context) must both be safe."""
+    import threading
+
+    path = str(synth.DATA / "6bft.pdb")
+    c = aa.Context(0)
+    for _ in range(3):
+        s = aa.load_model(path)
+        cols = c.get_contacts(s, "/", 0.1, 6.5)
+        del s  # arp_structure_free right behind the first call
+        assert len(cols["model"]) == 7236 and cols["from_chain"][0] != b""
+    results, errors = [None] * 4, []
+
+    def work(k):
+        try:
+            ctx_k = aa.Context(0)
+            st = aa.load_model(path if k % 2 == 0 else str(synth.DATA / "1ubq.pdb"))
+            results[k] = len(ctx_k.get_contacts(st, "/", 0.1, 6.5)["model"])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert results == [7236, 532, 7236, 532]
+
+
 def test_device_planes_phe4_of_1ubq(ctx):
     """the ring plane of PHE 4 as fitted ON THE DEVICE against the numbers of the reference's own unit test
     (residues.rs:355-372; the normal is defined up to sign, nalgebra's SVD returns the negated vector)."""
