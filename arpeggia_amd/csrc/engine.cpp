@@ -633,10 +633,12 @@ std::mutex g_shared_mu;
 std::unordered_map<const void *, SharedBlock *> g_shared_views;
 std::vector<SharedBlock *> g_shared_pool;
 size_t g_shared_pool_bytes = 0;
-// idle pinned memory kept for the next batch / table: 2 GiB unless ARPEGGIA_AMD_HOST_POOL_MB says otherwise (0 = keep nothing)
+// idle pinned memory kept for the next batch / table: 4 GiB unless ARPEGGIA_AMD_HOST_POOL_MB says otherwise (0 = keep nothing).  (2 GiB was
+// measured in round 4: a batch of 2048 five-thousand-atom structures with full candidate lists returns 2.3 GB of lists, the blocks beyond the
+// limit were unpinned and pinned again on every call -- 24 -> 41 us per structure.)
 const size_t kSharedPoolLimit = [] {
     const char *e = getenv("ARPEGGIA_AMD_HOST_POOL_MB");
-    const long long mb = e ? atoll(e) : 2048;
+    const long long mb = e ? atoll(e) : 4096;
     return (size_t)(mb < 0 ? 0 : mb) << 20;
 }();
 

@@ -19,6 +19,12 @@
 //     64-bit compare (complex.rs:108-130 for chain groups "/");
 //   * the prefilter runs in groups of 8 tests (lockstep granularity: a wave runs as long as its longest window) and
 //     compacts once per 32 tests.
+// Round 4 (profiles/r04_emit_experiments.txt, r04_issue_mix_microbench.txt): a scalar instruction is not free either -- it holds the SIMD's
+// one scalar issue slot for four cycles, as long as a half-rate vector instruction -- and round 3's batch ran ~74 of them.  The scalar diet:
+// masks straight out of VOP3 compares, one rare-path branch and a single exit per batch, the allocator's common case hand-scheduled, v_cmpx
+// compaction rounds, prefilter runs on immediate offsets; the short level count; 24-bit slot entries (one multiply to the gather offset).
+// What the time is made of now was measured by DOUBLING each class of work: the scattered gathers (21 us per million wave-loads), the LDS
+// reads (5.2) and every vector (0.63) or scalar (0.77) instruction add up to the kernel's time -- no single pipe binds.
 constexpr uint32_t kEChunk = 128;             // staged neighbour records per chunk
 constexpr int kEWaves = 12;                   // waves per block: two blocks per CU share the CU's LDS, 6 waves per SIMD
 constexpr uint32_t kEBlocks = 256u * 2u;
@@ -163,7 +169,7 @@ DEVFN void lm_store_records(lmask m, uint4 *base, uint32_t byte_off, const u32x4
 
 // The block allocator's common case without the compiler's help (round 3's form cost ~25 scalar instructions per batch: 64-bit
 // sign-extension of the two readfirstlanes, selects, a loop header).  alloc_issue_e: lane 0 adds n to the block's LDS word {chunk << 32 |
-// records used} -- exec is narrowed to lane 0 around the one instruction; the answer stays in lane 0's registers until alloc_take_e reads it.
+// records used} -- exec is narrowed to lane 0 around the one instruction; the answer stays in lane 0's registers until the batch's fast tail (exact_finish_e) or alloc_finish_rt reads it.
 DEVFN u32x2 alloc_issue_e(unsigned long long &state, uint32_t n) {
     const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)&state;
     u32x2 old, add = {n, 0u};
@@ -192,7 +198,7 @@ DEVFN void store_batch_general(const Slots &sl, lmask m_valid, uint32_t n_rec, u
 // computed -- and a pair that needs a probe is written with kind 0 at its final position and listed {slots, position} for
 // k_patch_deferred (pairs.inl).
 // Round 4 (scalar diet): one rare-path branch for "a probe decides" and "the square root needs the exact routine" together, the
-// allocator's common case in ~10 scalar instructions (alloc_take_e), masks straight out of the compares.
+// allocator's common case in ~10 scalar instructions (the asm block at the end of exact_finish_e), masks straight out of the compares.
 // The batch in two halves: exact_issue_e reads the batch's queue entries and sends the neighbour gathers on their way, exact_finish_e does
 // the rest (counters after the scalar diet: 54 % of wave-cycles at s_waitcnt).
 struct ExactRegs { uint32_t e; u32x4 bxy, bzp; unsigned long long kb; };
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
     const uint32_t probe_bits = in.n_res != 0u ? (1u << 29) : 0u;  // residue tables present: CYS SG pairs in the covalent band get their dihedral probe
     const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar, dprm->s_cov_max};
     const double r2m = gp->r2m;
-    // chunks that lie wholly inside the caller's buffer: a batch placed in one of them needs no further capacity test (alloc_take_e)
+    // chunks that lie wholly inside the caller's buffer: a batch placed in one of them needs no further capacity test (exact_finish_e's fast tail)
     // (and inside its first 2^32 bytes: the fast path addresses with a 32-bit byte offset; what lies beyond takes the general path)
     const uint32_t cap_chunks = (uint32_t)min(tg.capacity >> chunk_shift_of(kChunkE), (unsigned long long)((1u << 28) / kChunkE));
     WaveLdsE &w = wl[wave];

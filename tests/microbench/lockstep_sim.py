@@ -85,3 +85,45 @@ for wl,seed in (("s2", SEED+4), ("s1", SEED+3)):
     for grp,ch in ((8,128),(4,128),(2,128),(1,128),(8,256),(8,512)):
         i,u,c,nt = simulate(W,n,chunk=ch,group=grp)
         print(wl, 'group', grp, 'chunk', ch, 'issued/useful %.3f' % (i/u), 'chunks/task %.2f' % (c/nt))
+
+
+def windows_narrow(xyz, kx=4, cutoff=6.5):
+    """Per-lane narrowing of the x range of every window by what the home atom's position inside its cell leaves of the cutoff: an atom
+    of row (dy, dz) is at least m = [(1 - fy) or fy]^2 + (1 - fz)^2 cell edges away in the y-z plane, so only |dx| <= sqrt(r^2 - m) matters."""
+    edge = cutoff*(1+1e-6)
+    lo = xyz.min(0)
+    fx = (xyz[:,0]-lo[0])*kx/edge; fyv = (xyz[:,1]-lo[1])/edge; fzv = (xyz[:,2]-lo[2])/edge
+    cx = np.floor(fx).astype(np.int64); cy = np.floor(fyv).astype(np.int64); cz = np.floor(fzv).astype(np.int64)
+    nx, ny, nz = cx.max()+1, cy.max()+1, cz.max()+2
+    cell = (cz*ny+cy)*nx+cx
+    order = np.argsort(cell, kind='stable')
+    cell_s = cell[order]; n=len(cell_s)
+    start = np.searchsorted(cell_s, np.arange(nx*ny*nz+1))
+    cxs, cys, czs = cx[order], cy[order], cz[order]
+    fxs = fx[order]; fy = (fyv-cy)[order]; fz = (fzv-cz)[order]
+    W = np.zeros((5,n,2), dtype=np.int64)
+    xhi0 = np.minimum(cxs+kx, nx-1)
+    W[0,:,0] = np.arange(n)+1; W[0,:,1] = start[(czs*ny+cys)*nx+xhi0+1]
+    for k,(dy,dz) in enumerate([(1,0),(-1,1),(0,1),(1,1)], start=1):
+        m = np.zeros(n)
+        if dy == 1: m += (1-fy)**2
+        if dy == -1: m += fy**2
+        if dz == 1: m += (1-fz)**2
+        half = np.sqrt(np.maximum(1.0 - m, 0.0)) * kx * (1+1e-9)   # in x cells; m >= 1 -> nothing can be in range
+        xl = np.maximum(np.floor(fxs - half).astype(np.int64), 0); xh = np.minimum(np.floor(fxs + half).astype(np.int64), nx-1)
+        yy = cys+dy; zz = czs+dz
+        ok = (yy>=0)&(yy<ny)&(zz<nz)&(m < 1.0)
+        r = (zz*ny+np.clip(yy,0,ny-1))*nx
+        W[k,:,0] = np.where(ok, start[r+xl], 0); W[k,:,1] = np.where(ok, start[r+np.maximum(xh,xl)+1], 0)
+    return W, n
+
+
+print("--- per-lane narrowing of the x ranges (fixed chunks, 8-test groups)")
+for wl,seed in (("s2", SEED+4), ("s1", SEED+3)):
+    rec = getattr(synth, f"gen_{wl}")(60000, seed=seed)
+    heavy = rec["element"] != b"H"
+    xyz = np.stack([rec["x"], rec["y"], rec["z"]], 1)[heavy]
+    for name, fn in (("product", windows), ("narrowed", windows_narrow)):
+        W,n = fn(xyz)
+        i,u,c,nt = simulate(W,n)
+        print(wl, name, 'issued per lane %.1f  useful per lane %.1f  issued/useful %.3f  chunks/task %.2f' % (i/64/nt, u/64/nt, i/u, c/nt))

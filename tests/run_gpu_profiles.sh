@@ -16,3 +16,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format c
 python3 $GRAFT_REPO_ROOT/tests/trace_overlap.py $OUT/trace > $OUT/batch_overlap.txt 2>&1; cat $OUT/batch_overlap.txt
 rm -rf $OUT/trace/*/*kernel_trace.csv $OUT/trace/*/*memory_copy_trace.csv 2>/dev/null
 cd $GRAFT_REPO_ROOT && bash tests/run_gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary.txt; grep -A30 "k_emit<12, 1, false>" $OUT/pmc_summary.txt | head -32
+# the traffic / issue object of the bench line, tagged with the content hash of the sources this library was built from (bench.py checks it)
+PAIRS=$(python3 -c "import json; print(json.load(open('$OUT/bench.json'))['config']['pairs_per_gpu'])")
+python3 tests/pmc_to_json.py $OUT/pmc_summary.txt $OUT/traffic.json --pairs $PAIRS --source profiles/${TAG}_pmc_summary.txt
+for mode in deterministic contacts-only; do
+  timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --$mode > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err; python3 tests/show_bench.py $OUT/bench_$mode.json | head -2
+done
+timeout -k 10 300 python tests/sap_timing.py 100000 1000000 > $OUT/sap.txt 2>&1; tail -2 $OUT/sap.txt
+bash tests/microbench/sweep_sizes.sh > $OUT/sweep_sizes.txt 2>&1; tail -20 $OUT/sweep_sizes.txt
