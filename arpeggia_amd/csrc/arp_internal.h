@@ -12,7 +12,8 @@ namespace arp {
 // {s : sqrt(s) < T} = {s : s < lt(T)} with lt(T) = min{s : sqrt(s) >= T}; likewise d <= T  <=>  s < le(T).
 // The host computes lt/le exactly (engine.cpp: bound_lt / bound_le), so the device never needs a sqrt to decide.
 struct DevParams {
-    double r2;            // dist_cutoff^2, inclusive candidate test d^2 <= r2 (rstar locate_within_distance)
+    double r2;            // squared search radius, inclusive candidate test d^2 <= r2 (rstar locate_within_distance): r2_call, or less with
+                          // ARP_FLAG_CONTACTS_ONLY (no rule reaches further than the largest bound of the elements present) -- set by the grid sizing
     double s_ion;         // le(4.0)   ionic.rs:5, hbond.rs:7
     double s_polar;       // le(3.5)   hbond.rs:8
     double s_hphob;       // le(4.5)   hydrophobic.rs:5
@@ -20,9 +21,12 @@ struct DevParams {
     double s_cov[256];    // lt(cov[a]+cov[b] + c)   vdw.rs:34
     double s_vdw[256];    // lt(vdw[a]+vdw[b] + c)   vdw.rs:41
     double s_hacc[16];    // le(h_vdw + vdw[acceptor] + c)   hbond.rs:54,98
-    double s_cov_max;     // the largest s_cov[] of all element pairs: below it a candidate MAY be inside a covalent / clash band (k_emit's short level count)
-    float r2f;            // prefilter threshold in f32 (r2 + margin), set by the grid setup kernel
+    double s_cov_max;     // the largest s_cov[] of the element pairs PRESENT: below it a candidate MAY be inside a covalent / clash band (k_emit's short level
+                          // count) -- set by the grid sizing
+    float r2f;            // prefilter threshold in f32 (r2 + margin), set by the grid sizing
     uint32_t flags;       // arp_params.flags (ARP_FLAG_CONTACTS_ONLY is read by the pair kernels)
+    double r2_call;       // dist_cutoff^2 (complex.rs:191) as the caller gave it.  Everything but r2, r2f and s_cov_max is constant for a given
+                          // arp_params: the device copy is uploaded when the parameters change, not per call
 };
 
 // Uniform grid, written by the device-side setup kernel (no host round trip).
@@ -142,8 +146,8 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
 void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out, bool contacts_only);
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof,
                          bool contacts_only);
-void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
-                 bool skip_deferred);
+bool launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+                 bool skip_deferred);  // true: the hole-free sequence of small inputs ran (the host derives result[0] and the flags: engine.cpp finish_result)
 unsigned long long emit_scratch_records();
 void launch_neighbor_sum(const DevAtoms &in, const Workspace &ws, double radius, double r2, const float *weight, float *out, hipStream_t st, Profiler *prof);
 void launch_pack_fix(const PackArrays &pa, hipStream_t st);

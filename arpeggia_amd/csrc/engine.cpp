@@ -69,7 +69,7 @@ double bound_le(double T) {
 void make_dev_params(const arp_params &p, DevParams *d) {
     memset(d, 0, sizeof *d);
     const double c = p.vdw_comp;
-    d->r2 = p.dist_cutoff * p.dist_cutoff;  // complex.rs:191
+    d->r2 = d->r2_call = p.dist_cutoff * p.dist_cutoff;  // complex.rs:191 (r2 itself is rewritten by every call's grid sizing)
     d->s_ion = bound_le(4.0);
     d->s_polar = bound_le(3.5);
     d->s_hphob = bound_le(4.5);
@@ -128,8 +128,11 @@ struct arp_context {
     // with the pass.  A guess that is checked on the device, never a correctness assumption.
     const double *nodefer_x = nullptr; uint64_t nodefer_n = 0;
     bool last_skip = false;
+    bool last_direct = false;  // the enqueued call ran the hole-free sequence of small inputs (launch_emit): finish_result derives what k_fixup would have published
     arp_params last_params{};
     bool have_params = false;
+    DevParams *params_on_device = nullptr;  // the workspace block that holds the current parameters (upload_params); reset with the workspace
+    hipStream_t params_stream = nullptr;    // ... uploaded on this stream (a caller who swaps streams gets a fresh upload, ordered on the new one)
     uint64_t last_capacity = 0;
     bool pending = false;
     char *scr_dev[2] = {nullptr, nullptr}, *scr_pin[2] = {nullptr, nullptr};  // table path: two grow-only scratch blocks (device / pinned)
@@ -158,7 +161,7 @@ static arp_status dev_alloc(arp_context *ctx, T **p, size_t count) {
 }
 
 static void free_workspace(arp_context *ctx) {
-    ctx->grid_x = nullptr; ctx->grid_n = 0;
+    ctx->grid_x = nullptr; ctx->grid_n = 0; ctx->params_on_device = nullptr;
     for (void *p : ctx->ws_allocs) (void)hipFree(p);
     ctx->ws_allocs.clear();
     ctx->ws = Workspace{};
@@ -326,15 +329,32 @@ static arp_status stage_inputs(arp_context *ctx, const arp_atoms *a, DevAtoms *d
 }
 
 static arp_status upload_params(arp_context *ctx, const arp_params *p) {
+    // The device copy is uploaded when the parameters (or the workspace it lives in) change, not per call: the three fields a call derives
+    // from its input (DevParams::r2, r2f, s_cov_max) are rewritten by every call's grid sizing from fields that nothing on the device writes.
     if (!ctx->have_params || memcmp(&ctx->last_params, p, sizeof *p) != 0) {
-        // the pinned buffer may still be in flight from the previous call
+        // the pinned buffer may still be in flight from the previous upload
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         make_dev_params(*p, ctx->h_params);
         ctx->last_params = *p;
         ctx->have_params = true;
+        ctx->params_on_device = nullptr;
     }
-    HIP_TRY(hipMemcpyAsync(ctx->ws.params, ctx->h_params, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->params_on_device != ctx->ws.params || ctx->params_stream != ctx->stream) {
+        HIP_TRY(hipMemcpyAsync(ctx->ws.params, ctx->h_params, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+        ctx->params_on_device = ctx->ws.params; ctx->params_stream = ctx->stream;
+    }
     return ARP_OK;
+}
+
+// After the four result words of a single-pass call have arrived.  The hole-free sequence of small inputs (launch_emit returned true) has no
+// fix-up kernel to publish the pair count and the flags that depend on it: the records lie back to back from position 0 and result[2] counts
+// them, result[3] the chunks of the deferred list (the input-error flags were set by the grid sizing).
+static void finish_result(arp_context *ctx, bool direct, bool skipped, unsigned long long capacity) {
+    if (!direct) return;
+    unsigned long long *r = ctx->h_result;
+    r[0] = r[2];
+    if (r[0] > capacity) r[1] |= 1ull;                // the list did not fit (k_fixup: P > capacity)
+    if (skipped && r[3] != 0ull) r[1] |= 128ull;      // the probe pass was skipped on a memo that no longer holds
 }
 
 constexpr arp_status kRetryDefer = -1;      // internal: never crosses the C ABI
@@ -454,6 +474,7 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
     const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
     launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
+    bool direct = false;
     if (!out || capacity == 0) {
         launch_count(d, ctx->ws, ctx->stream, prof, 0, true, only);  // size query: reports ARP_ERR_CAPACITY + the count
     } else if (params->flags & ARP_FLAG_DETERMINISTIC) {
@@ -461,8 +482,9 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
         launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof, only);
     } else {
         ctx->last_skip = !(params->flags & ARP_FLAG_NO_SPECULATION) && skip_deferred_pass(ctx, d);
-        launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only, ctx->last_skip);
+        direct = launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only, ctx->last_skip);
     }
+    ctx->last_direct = direct;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     ctx->last_capacity = capacity;
@@ -478,6 +500,7 @@ extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_p
     for (;;) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->pending = false;
+        finish_result(ctx, ctx->last_direct, ctx->last_skip, ctx->last_capacity);
         if (n_pairs) *n_pairs = ctx->h_result[0];
         const arp_atoms again = ctx->last_atoms;
         const arp_params prm = ctx->last_params;
@@ -518,10 +541,11 @@ static arp_status single_pass_into_context_buffer(arp_context *ctx, uint64_t n_a
         }
         launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false); ctx->grid_x = d.x; ctx->grid_n = d.n;
         const bool skip = skip_deferred_pass(ctx, d);
-        launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0, skip);
+        const bool direct = launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0, skip);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        finish_result(ctx, direct, skip, ctx->out_cap);
         note_deferred(ctx, d, skip);
         if ((s = flags_to_status(ctx->h_result[1])) == kRetryDeferPass) { attempt--; continue; }  // the memo was stale: once more, with the probe pass
         if (s != ARP_OK) return s;
@@ -602,11 +626,13 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     if (total == 0) return ARP_OK;
     arp_pair *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
+    bool direct = false;
     if (params->flags & ARP_FLAG_DETERMINISTIC) launch_fill_ordered(d, ctx->ws, dev, total, ctx->stream, prof, only);
-    else launch_emit(d, ctx->ws, dev, total, ctx->stream, prof, only, false);
+    else direct = launch_emit(d, ctx->ws, dev, total, ctx->stream, prof, only, false);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) finish_result(ctx, direct, false, total);
     if (e != hipSuccess) { (void)hipFree(dev); set_error("HIP error %d (%s) in the fill pass", (int)e, hipGetErrorString(e)); return ARP_ERR_HIP; }
     if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) { (void)hipFree(dev); return s; }
     total = std::min<unsigned long long>(total, ctx->h_result[0]);  // fewer than the candidates with ARP_FLAG_CONTACTS_ONLY

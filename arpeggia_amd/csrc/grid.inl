@@ -1,16 +1,17 @@
 // Uniform-grid (cell list) construction.  Included by kernels.hip inside namespace arp.
 //
-//   k_bounds + k_setup   bounding box of the heavy atoms, then one block sizes the grid (no host round trip)
-//   k_cellid   cell of every atom + its arrival rank in the cell (one returning atomic per RUN of same-cell atoms in a wave)
-//   scan       cell_count -> cell_start (three launches; the last one also clears cell_count for the next call)
+//   k_bounds   bounding box of the heavy atoms as per-block partial results
+//   k_cellid   sizes the grid from those (every block for itself, block 0 publishes: no launch of its own for one block's work), then the cell
+//              of every atom + its arrival rank in the cell (one returning atomic per distinct cell of a block).  Inputs of a few thousand
+//              atoms skip k_bounds as well: every block of k_cellid reads all the atoms.  Packed batches size their grid per model in k_setup.
+//   scan       cell_count -> cell_start: one block while the cells fit its registers, two launches beyond; clears cell_count for the next call
 //   k_place    emit mode: each atom writes its records straight to slot cell_start + arrival rank (coalesced reads)
 //   k_scatter + k_gather   ordered mode: slots inside a cell follow the atom index, so the emitted order is reproducible
 
 // ---------------------------------------------------------------------------------------------- bounds + grid setup
-constexpr uint32_t kBoundsBlocks = 1024;
-
-DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, uint32_t n_models, uint32_t bad, GridParams *g, DevParams *prm,
-                      double cutoff, uint32_t ncells_cap, uint32_t n_atoms) {
+// (r2 = the call's squared search radius; returns the f32 prefilter threshold of the two-pass kernels, DevParams::r2f)
+DEVFN float grid_setup(const double lo_in[3], const double hi_in[3], bool empty, uint32_t n_models, uint32_t bad, GridParams *g, double r2,
+                       double cutoff, uint32_t ncells_cap, uint32_t n_atoms) {
     double lo[3], ext[3];
     for (int k = 0; k < 3; k++) {
         lo[k] = empty ? 0.0 : lo_in[k];
@@ -56,25 +57,28 @@ DEVFN void grid_setup(const double lo_in[3], const double hi_in[3], bool empty, 
     // f32 prefilter: relative coordinates carry <= 2^-24 * extent of rounding each; a 10x-safe bound on the
     // induced error of dx^2+dy^2+dz^2 near the cutoff (derivation in DESIGN.md "Prefilter margin")
     const double M = fmax(ext[0], fmax(ext[1], ext[2])) + edge;
-    const double margin = 4e-6 * (prm->r2 + fabs(cutoff) * M) + 1e-6;
+    const double margin = 4e-6 * (r2 + fabs(cutoff) * M) + 1e-6;
     g->prefilter_margin = (float)margin;
-    prm->r2f = __double2float_ru(prm->r2 + margin);
     // The test is evaluated as |n|^2 - 2 n.h <= thr - |h|^2 (3 FMAs instead of 3 subtractions + 3 multiply-adds) on records
     // centred on the box midpoint, |coordinate| <= C = M / 2.  Rounding of the stored |n|^2 and of the three FMAs moves the
     // left side by at most 24 * 2^-24 * C^2 (DESIGN.md "Prefilter margin"); twice that is added to the threshold.
     for (int k = 0; k < 3; k++) (&g->mx)[k] = lo[k] + 0.5 * ext[k];
     const double C = 0.5 * M;
-    g->r2m = prm->r2 + margin + 3e-6 * C * C;
+    g->r2m = r2 + margin + 3e-6 * C * C;
+    return __double2float_ru(r2 + margin);
 }
 
-// Bounding box in two launches: per-block partial results with plain stores, then one block reduces them and sizes the grid.
+// Bounding box: per-block partial results with plain stores; the blocks of the NEXT kernel reduce them (k_cellid, or k_setup for packs).
 // (A single launch with an arrival ticket was measured 2-3x slower: the per-block device-scope atomics / write-through
 // stores cost more than the extra launch.)  partials: [kBoundsBlocks][8] doubles = {min xyz, max xyz, models, bad}.
+constexpr uint32_t kBoundsBlocks = 256, kBoundsThreads = 1024;
 struct BoxAcc {
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t models = 0, bad = 0;
 };
-DEVFN void box_block_reduce(BoxAcc &a, double (*s_mn)[3], double (*s_mx)[3], uint32_t *s_models, uint32_t *s_bad) {
+struct BoxLds { double mn[kBoundsThreads / 64][3], mx[kBoundsThreads / 64][3]; uint32_t models[kBoundsThreads / 64], bad[kBoundsThreads / 64]; };
+template <uint32_t NW>
+DEVFN void box_block_reduce(BoxAcc &a, BoxLds &l) {
     for (int off = 32; off; off >>= 1) {
         for (int k = 0; k < 3; k++) {
             a.mn[k] = fmin(a.mn[k], __shfl_xor(a.mn[k], off));
@@ -86,26 +90,21 @@ DEVFN void box_block_reduce(BoxAcc &a, double (*s_mn)[3], double (*s_mx)[3], uin
     const uint32_t w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 3; k++) { s_mn[w][k] = a.mn[k]; s_mx[w][k] = a.mx[k]; }
-        s_models[w] = a.models; s_bad[w] = a.bad;
+        for (int k = 0; k < 3; k++) { l.mn[w][k] = a.mn[k]; l.mx[w][k] = a.mx[k]; }
+        l.models[w] = a.models; l.bad[w] = a.bad;
     }
     __syncthreads();
-    for (int k = 0; k < 3; k++) {
-        a.mn[k] = fmin(fmin(s_mn[0][k], s_mn[1][k]), fmin(s_mn[2][k], s_mn[3][k]));
-        a.mx[k] = fmax(fmax(s_mx[0][k], s_mx[1][k]), fmax(s_mx[2][k], s_mx[3][k]));
+    for (uint32_t v = 0; v < NW; v++) {
+        for (int k = 0; k < 3; k++) { a.mn[k] = fmin(a.mn[k], l.mn[v][k]); a.mx[k] = fmax(a.mx[k], l.mx[v][k]); }
+        a.models = max(a.models, l.models[v]); a.bad |= l.bad[v];
     }
-    a.models = max(max(s_models[0], s_models[1]), max(s_models[2], s_models[3]));
-    a.bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
 }
 
-__global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
-    __shared__ double s_mn[4][3], s_mx[4][3];
-    __shared__ uint32_t s_models[4], s_bad[4];
-    BoxAcc acc;
-    // Four independent atoms per trip, loaded UNCONDITIONALLY from a clamped index: predicated loads make hipcc wait for
-    // each attr word before issuing the next atom's loads, which turns the loop into serial round trips.
-    const uint32_t stride = gridDim.x * blockDim.x, last = in.n ? in.n - 1u : 0u;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < in.n; i0 += 4u * stride) {
+// atoms i0, i0 + stride, ... into the thread's accumulators.  Four independent atoms per trip, loaded UNCONDITIONALLY from a clamped index:
+// predicated loads make hipcc wait for each attr word before issuing the next atom's loads, which turns the loop into serial round trips.
+DEVFN void box_accumulate(const DevAtoms &in, uint32_t first, uint32_t stride, BoxAcc &acc) {
+    const uint32_t last = in.n ? in.n - 1u : 0u;
+    for (uint32_t i0 = first; i0 < in.n; i0 += 4u * stride) {
         double p[4][3];
         uint32_t at[4], md[4];
 #pragma unroll
@@ -127,7 +126,20 @@ __global__ __launch_bounds__(256) void k_bounds(DevAtoms in, double *partials) {
             acc.bad |= (use & ((at[u] & (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR)) != (ARP_ATTR_LIGAND | ARP_ATTR_RECEPTOR))) ? (1u << 24) : 0u;  // bit 24: an atom outside L or R
         }
     }
-    box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
+}
+DEVFN void box_from_partials(const double *partials, uint32_t n_partials, BoxAcc &acc) {
+    for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {
+        const double *p = partials + 8 * b;
+        for (int k = 0; k < 3; k++) { acc.mn[k] = fmin(acc.mn[k], p[k]); acc.mx[k] = fmax(acc.mx[k], p[3 + k]); }
+        acc.models = max(acc.models, (uint32_t)p[6]); acc.bad |= (uint32_t)p[7];
+    }
+}
+
+__global__ __launch_bounds__(kBoundsThreads) void k_bounds(DevAtoms in, double *partials) {
+    __shared__ BoxLds l;
+    BoxAcc acc;
+    box_accumulate(in, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, acc);
+    box_block_reduce<kBoundsThreads / 64>(acc, l);
     if (threadIdx.x == 0) {
         double *p = partials + 8 * blockIdx.x;
         for (int k = 0; k < 3; k++) { p[k] = acc.mn[k]; p[3 + k] = acc.mx[k]; }
@@ -162,78 +174,89 @@ __global__ __launch_bounds__(256) void k_model_bounds(DevAtoms in, uint32_t *box
     }
 }
 
-__global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t n_partials, GridParams *g, DevParams *prm, double cutoff,
-                                               uint32_t ncells_cap, uint32_t n_atoms, unsigned long long *result, uint32_t *task_ctr, const uint32_t *model_box, double *model_org) {
-    __shared__ double s_mn[4][3], s_mx[4][3];
-    __shared__ uint32_t s_models[4], s_bad[4];
-    for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
-    if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results
-    BoxAcc acc;
-    for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {
-        const double *p = partials + 8 * b;
-        for (int k = 0; k < 3; k++) { acc.mn[k] = fmin(acc.mn[k], p[k]); acc.mx[k] = fmax(acc.mx[k], p[3 + k]); }
-        acc.models = max(acc.models, (uint32_t)p[6]); acc.bad |= (uint32_t)p[7];
+// Sizes the grid from a block's box accumulators.  Called by all 256 threads of a block; on return (behind a barrier) l.g holds the grid
+// parameters.  Every block of k_cellid does this for itself -- the inputs are a few KB out of the L2 and the work is one thread's -- which
+// saves the launch a single-block kernel would cost; the block with `publish` also writes the grid, the call's derived parameters
+// (DevParams::r2, r2f, s_cov_max) and the per-call zeroes to global memory for the kernels that follow.  Nothing read here is written here:
+// the caller's squared cutoff stays in DevParams::r2_call.
+struct SetupLds { BoxLds box; double red[4]; double ext[4][3]; GridParams g; };
+DEVFN void setup_block(BoxAcc &acc, SetupLds &l, bool publish, GridParams *g, DevParams *prm, double cutoff, uint32_t ncells_cap, uint32_t n_atoms,
+                       unsigned long long *result, uint32_t *task_ctr, const uint32_t *model_box, double *model_org) {
+    if (publish) {
+        for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
+        if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results
     }
-    box_block_reduce(acc, s_mn, s_mx, s_models, s_bad);
+    box_block_reduce<4>(acc, l.box);
+    auto block_max = [&](double b) {
+        for (int off = 32; off; off >>= 1) b = fmax(b, __shfl_xor(b, off));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) l.red[threadIdx.x >> 6] = b;
+        __syncthreads();
+        return fmax(fmax(l.red[0], l.red[1]), fmax(l.red[2], l.red[3]));
+    };
+    const uint32_t present = (acc.bad >> 8) & 0xFFFFu, ea = threadIdx.x >> 4, eb = threadIdx.x & 15u;
+    const bool pair_present = (present >> ea) & (present >> eb) & 1u;
     // the largest covalent bound among the element pairs that are PRESENT (k_emit's short level count: a candidate above it is in no
     // covalent or clash band; the parameter table also holds the metals' radii, which would put every other candidate below it)
-    {
-        __shared__ double s_cmax[4];
-        const uint32_t present = (acc.bad >> 8) & 0xFFFFu, ea = threadIdx.x >> 4, eb = threadIdx.x & 15u;
-        double b = ((present >> ea) & (present >> eb) & 1u) ? prm->s_cov[threadIdx.x] : 0.0;
-        for (int off = 32; off; off >>= 1) b = fmax(b, __shfl_xor(b, off));
-        if ((threadIdx.x & 63) == 0) s_cmax[threadIdx.x >> 6] = b;
-        __syncthreads();
-        if (threadIdx.x == 0) prm->s_cov_max = fmax(fmax(s_cmax[0], s_cmax[1]), fmax(s_cmax[2], s_cmax[3]));
-    }
+    const double cov_max = block_max(pair_present ? prm->s_cov[threadIdx.x] : 0.0);
     // ARP_FLAG_CONTACTS_ONLY: no rule can match beyond the largest decision bound of the element pairs that are present
     // (every rule of classify() is `s < bound`), so the search radius shrinks to it -- for C/N/O/S that is the 4.5 A of the
     // hydrophobic rule -- and the dropped candidates are exactly ones the flag would have filtered out.
-    __shared__ double s_bound[4];
+    double r2 = prm->r2_call;
     if (prm->flags & ARP_FLAG_CONTACTS_ONLY) {
-        const uint32_t present = (acc.bad >> 8) & 0xFFFFu, ea = threadIdx.x >> 4, eb = threadIdx.x & 15u;
         double b = fmax(prm->s_hphob, fmax(prm->s_ion, prm->s_polar));
-        if ((present >> ea) & (present >> eb) & 1u) b = fmax(b, fmax(prm->s_clash[threadIdx.x], fmax(prm->s_cov[threadIdx.x], prm->s_vdw[threadIdx.x])));
-        for (int off = 32; off; off >>= 1) b = fmax(b, __shfl_xor(b, off));
-        if ((threadIdx.x & 63) == 0) s_bound[threadIdx.x >> 6] = b;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            b = fmax(fmax(s_bound[0], s_bound[1]), fmax(s_bound[2], s_bound[3]));
-            if (b < prm->r2) { prm->r2 = b; cutoff = sqrt(b); }
-        }
+        if (pair_present) b = fmax(b, fmax(prm->s_clash[threadIdx.x], fmax(prm->s_cov[threadIdx.x], prm->s_vdw[threadIdx.x])));
+        b = block_max(b);
+        if (b < r2) { r2 = b; cutoff = sqrt(b); }
     }
     // Packed batch: the grid is sized by the LARGEST member and every model gets its own origin (its box's min corner) and
     // its own midpoint for the f32 records -- members may sit anywhere in space without inflating the cell count.
-    __shared__ double s_ext[4][3];
-    if (model_box) {
-        double ext[3] = {0.0, 0.0, 0.0};  // (differences of f32 values are exact in f64)
+    double ext[3] = {0.0, 0.0, 0.0};
+    if (model_box) {  // (differences of f32 values are exact in f64)
         for (uint32_t m = threadIdx.x; m < acc.models; m += blockDim.x) {
             const uint32_t *b = model_box + 6u * m;
             if (b[0] == 0xFFFFFFFFu) continue;  // no heavy atom in this model
             for (int k = 0; k < 3; k++) ext[k] = fmax(ext[k], (double)f32_decode(b[3 + k]) - (double)f32_decode(b[k]));
         }
         for (int off = 32; off; off >>= 1) for (int k = 0; k < 3; k++) ext[k] = fmax(ext[k], __shfl_xor(ext[k], off));
-        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; k++) s_ext[threadIdx.x >> 6][k] = ext[k];
         __syncthreads();
-        for (int k = 0; k < 3; k++) ext[k] = fmax(fmax(s_ext[0][k], s_ext[1][k]), fmax(s_ext[2][k], s_ext[3][k]));
-        for (uint32_t m = threadIdx.x; m < acc.models; m += blockDim.x) {
-            const uint32_t *b = model_box + 6u * m;
-            double *o = model_org + 6u * m;
-            for (int k = 0; k < 3; k++) {
-                const double lo = b[0] == 0xFFFFFFFFu ? 0.0 : (double)f32_decode(b[k]);
-                o[k] = lo; o[3 + k] = lo + 0.5 * ext[k];
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; k++) l.ext[threadIdx.x >> 6][k] = ext[k];
+        __syncthreads();
+        for (int k = 0; k < 3; k++) ext[k] = fmax(fmax(l.ext[0][k], l.ext[1][k]), fmax(l.ext[2][k], l.ext[3][k]));
+        if (publish)
+            for (uint32_t m = threadIdx.x; m < acc.models; m += blockDim.x) {
+                const uint32_t *b = model_box + 6u * m;
+                double *o = model_org + 6u * m;
+                for (int k = 0; k < 3; k++) {
+                    const double lo = b[0] == 0xFFFFFFFFu ? 0.0 : (double)f32_decode(b[k]);
+                    o[k] = lo; o[3 + k] = lo + 0.5 * ext[k];
+                }
             }
-        }
-        if (threadIdx.x == 0) {
-            const double zero[3] = {0.0, 0.0, 0.0}, hi[3] = {ext[0], ext[1], ext[2]};
-            grid_setup(zero, hi, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap, n_atoms);
-            g->model_org = model_org;
-        }
-    } else if (threadIdx.x == 0) {
-        grid_setup(acc.mn, acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, g, prm, cutoff, ncells_cap, n_atoms);
-        g->model_org = nullptr;
     }
-    if (threadIdx.x == 0) g->all_both = (acc.bad >> 24) & 1u ? 0u : 1u;
+    if (threadIdx.x == 0) {
+        GridParams gl;
+        const double zero[3] = {0.0, 0.0, 0.0};
+        const float r2f = grid_setup(model_box ? zero : acc.mn, model_box ? ext : acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, &gl, r2, cutoff, ncells_cap, n_atoms);
+        gl.model_org = model_box ? model_org : nullptr;
+        gl.all_both = (acc.bad >> 24) & 1u ? 0u : 1u;
+        l.g = gl;
+        if (publish) {
+            *g = gl; prm->r2 = r2; prm->r2f = r2f; prm->s_cov_max = cov_max;
+            // the input errors as status flags right away (k_fixup and the count scan set them again; the hole-free sequence of small inputs has neither)
+            const unsigned long long fl = ((gl.bad & 1u) ? 4ull : 0ull) | ((gl.bad & 2u) ? 64ull : 0ull);
+            if (fl) atomicOr(&result[1], fl);
+        }
+    }
+    __syncthreads();
+}
+
+// The grid sizing as a kernel of its own: packed batches (the per-model boxes have to be complete first) and empty inputs.
+__global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t n_partials, GridParams *g, DevParams *prm, double cutoff,
+                                               uint32_t ncells_cap, uint32_t n_atoms, unsigned long long *result, uint32_t *task_ctr, const uint32_t *model_box, double *model_org) {
+    __shared__ SetupLds l;
+    BoxAcc acc;
+    box_from_partials(partials, n_partials, acc);
+    setup_block(acc, l, true, g, prm, cutoff, ncells_cap, n_atoms, result, task_ctr, model_box, model_org);
 }
 
 DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
@@ -254,20 +277,33 @@ DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uin
 // a lattice column), so each distinct cell of the block costs ONE returning device atomic -- scattered device atomics are what
 // bounds this kernel (about 14 per ns over the whole chip).  rank = the cell's base for this block + the arrival rank in the block.
 constexpr uint32_t kCidThreads = 256, kCidPer = 4, kCidTable = 2048;
-__global__ __launch_bounds__(kCidThreads) void k_cellid(DevAtoms in, const GridParams *gp, uint32_t *cell_of_atom, uint32_t *rank_of_atom,
-                                                        uint32_t *cell_count) {
+// BOX: where the grid parameters come from.  0 = *gp, written by k_setup (packed batches); 1 = this block sizes the grid from k_bounds'
+// partial boxes; 2 = from all the atoms, read by this block itself (inputs of a few thousand atoms: a handful of blocks, each a few trips
+// over arrays that sit in the L2 -- two launches less on a call that is a chain of launches and little else).  Block 0 publishes.
+constexpr uint32_t kCidAllAtoms = 12288;  // BOX = 2 up to here (launch_grid)
+template <int BOX>
+__global__ __launch_bounds__(kCidThreads, 4) void k_cellid(DevAtoms in, GridParams *gp, DevParams *prm, const double *partials, uint32_t n_partials, double cutoff,
+                                                        uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr, uint32_t *cell_of_atom,
+                                                        uint32_t *rank_of_atom, uint32_t *cell_count) {
     __shared__ uint32_t t_key[kCidTable], t_cnt[kCidTable];
+    __shared__ SetupLds sl;
     for (uint32_t k = threadIdx.x; k < kCidTable; k += kCidThreads) { t_key[k] = ARP_NONE; t_cnt[k] = 0u; }
-    const GridParams g = *gp;
     const uint32_t i0 = blockIdx.x * (kCidThreads * kCidPer) + threadIdx.x, last = in.n - 1u;  // (never launched with n == 0)
     double p[kCidPer][3];
     uint32_t at[kCidPer], md[kCidPer];
 #pragma unroll
-    for (uint32_t u = 0; u < kCidPer; u++) {  // unconditional loads from a clamped index: all of them in flight together
+    for (uint32_t u = 0; u < kCidPer; u++) {  // unconditional loads from a clamped index: all of them in flight together (and during the grid sizing)
         const uint32_t i = min(i0 + u * kCidThreads, last);
         at[u] = in.attr[i]; md[u] = (uint32_t)in.model[i];
         p[u][0] = in.x[i]; p[u][1] = in.y[i]; p[u][2] = in.z[i];
     }
+    if (BOX != 0) {
+        BoxAcc acc;
+        if (BOX == 1) box_from_partials(partials, n_partials, acc);
+        else box_accumulate(in, threadIdx.x, kCidThreads, acc);
+        setup_block(acc, sl, blockIdx.x == 0u, gp, prm, cutoff, ncells_cap, in.n, result, task_ctr, nullptr, nullptr);
+    }
+    const GridParams g = BOX != 0 ? sl.g : *gp;
     __syncthreads();
     uint32_t c[kCidPer], slot[kCidPer], r[kCidPer];
 #pragma unroll
@@ -382,6 +418,65 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
             if (g->bad & 2u) result[1] |= 64ull;
         }
     }
+}
+
+// The cell scan in ONE launch for inputs whose cells fit one workgroup's registers (launch_grid: up to kScanOneAtoms atoms, i.e. <= 65536
+// cells at the 0.35 cells per atom the grid sizing allows): wave w owns 4096 consecutive cells per pass -- 16 coalesced 16-byte loads per
+// lane, all in flight together --, scans them with the DPP row shifts (no LDS round trips), and one barrier exchanges the 16 wave totals.
+// A sparse input with more cells than that takes further passes (correct, just slower than the two-launch scan the launcher would have
+// picked had it known: the cell count only exists on the device).
+constexpr uint32_t kScanOneThreads = 1024, kScanOnePer = 16, kScanOneCells = kScanOneThreads * kScanOnePer * 4u, kScanOneAtoms = 180000;
+DEVFN uint32_t wave_inclusive_add_u32(uint32_t v) {  // (the scan wave_reduce_u32 is the last lane of)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+template <bool ZERO_IN>
+__global__ __launch_bounds__(kScanOneThreads) void k_scan_one(uint32_t *in, const uint32_t *n_ptr, uint32_t *out) {
+    __shared__ uint32_t wave_total[kScanOneThreads / 64];
+    const uint32_t n = *n_ptr, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += kScanOneCells) {
+        const uint32_t w0 = base + wave * (kScanOnePer * 256u) + lane * 4u;
+        uint4 v[kScanOnePer];
+#pragma unroll
+        for (uint32_t j = 0; j < kScanOnePer; j++) {
+            const uint32_t i = w0 + j * 256u;
+            v[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i + 4u <= n) v[j] = *reinterpret_cast<const uint4 *>(in + i);
+            else if (i < n) { v[j].x = in[i]; if (i + 1u < n) v[j].y = in[i + 1u]; if (i + 2u < n) v[j].z = in[i + 2u]; }
+        }
+        uint32_t ex[kScanOnePer], run = 0;  // ex[j]: cells before this lane's four of trip j, inside the wave's stretch
+#pragma unroll
+        for (uint32_t j = 0; j < kScanOnePer; j++) {
+            const uint32_t s = v[j].x + v[j].y + v[j].z + v[j].w, inc = wave_inclusive_add_u32(s);
+            ex[j] = run + inc - s;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        __syncthreads();  // (the previous pass is done with wave_total)
+        if (lane == 0u) wave_total[wave] = run;
+        __syncthreads();
+        uint32_t before = carry, pass = 0;
+        for (uint32_t k = 0; k < kScanOneThreads / 64u; k++) { const uint32_t t = wave_total[k]; if (k < wave) before += t; pass += t; }
+#pragma unroll
+        for (uint32_t j = 0; j < kScanOnePer; j++) {
+            const uint32_t i = w0 + j * 256u, o = before + ex[j];
+            const uint4 r = make_uint4(o, o + v[j].x, o + v[j].x + v[j].y, o + v[j].x + v[j].y + v[j].z);
+            if (i + 4u <= n) {
+                *reinterpret_cast<uint4 *>(out + i) = r;
+                if (ZERO_IN) *reinterpret_cast<uint4 *>(in + i) = make_uint4(0u, 0u, 0u, 0u);
+            } else if (i < n) {
+                out[i] = r.x; if (i + 1u < n) out[i + 1u] = r.y; if (i + 2u < n) out[i + 2u] = r.z;
+                if (ZERO_IN) { in[i] = 0u; if (i + 1u < n) in[i + 1u] = 0u; if (i + 2u < n) in[i + 2u] = 0u; }
+            }
+        }
+        carry += pass;
+    }
+    if (threadIdx.x == 0u) out[n] = carry;
 }
 
 // ---------------------------------------------------------------------------------------------- sort into cells

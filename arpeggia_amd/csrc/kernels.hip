@@ -9,6 +9,7 @@
 // contraction (this file is compiled with -ffp-contract=off); an f32 test with a proven margin only prefilters.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "arp_internal.h"
 

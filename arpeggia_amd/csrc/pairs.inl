@@ -36,7 +36,7 @@ constexpr uint32_t kESlotBits = 24;        // k_emit (pairs_emit.inl): neighbour
 // records per global allocation (one device atomic each).  The wave whose allocation crosses the end of the block's chunk fetches the
 // next one while the block's other waves sleep: 2048 -> 4096 halves those stalls (emit 221 -> 208 us); 8192 gains 2 us more and costs
 // the fix-up 8 us (holes grow with the chunk).
-constexpr uint32_t kChunkRecords = 4096, kSmallChunkRecords = 2048, kTinyChunkRecords = 256;  // records per allocation chunk (powers of two; the smaller ones: k_emit's 4-wave kernels)
+constexpr uint32_t kChunkRecords = 4096, kSmallChunkRecords = 2048, kTinyChunkRecords = 256;  // records per allocation chunk (powers of two; the smaller ones: k_emit's 4-wave kernels; the smallest inputs allocate per batch)
 
 template <int MODE>
 struct WaveLds {                                  // per-wave LDS working set
@@ -153,7 +153,16 @@ template <uint32_t CHUNK>
 DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane) {
     return alloc_finish<CHUNK>(state, g_head, n, lane, alloc_issue(state, n, lane));
 }
+// The hole-free sequence of small inputs (k_emit's DIRECT kernels stage their records in LDS and take the places of a whole flush at once; the
+// probe pass behind them allocates per batch): n places straight from the global counter, which then counts RECORDS -- a few hundred
+// returning atomics per call, all on one address (~11 ns each when they queue up), instead of a fix-up launch behind the sequence.
+DEVFN Slots alloc_direct(unsigned long long *g_head, uint32_t n, uint32_t lane) {
+    unsigned long long p = 0;
+    if (lane == 0) p = atomicAdd(g_head, (unsigned long long)n);
+    return Slots{wave_first_u64(p), 0ull, n};
+}
 DEVFN Slots alloc_chunked_rt(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane, uint32_t shift) {
+    if (shift == 0u) return alloc_direct(g_head, n, lane);  // (wave-uniform: the block's chunk_shift)
     return alloc_finish_rt(state, g_head, n, lane, alloc_issue(state, n, lane), shift);
 }
 
@@ -649,21 +658,31 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
     auto P0 = [&](const char *nm) { if (prof) prof->begin(nm, st); };
     auto P1 = [&]() { if (prof) prof->end(st); };
     if (prof) prof->n = 0;
+    // One structure: the blocks of k_cellid size the grid themselves (grid.inl setup_block), and below kCidAllAtoms atoms they also find the box.
+    // Packed batches keep the launch of their own (per-model boxes first), and so does the empty input (no k_cellid to fold into).
+    const bool fold = n != 0u && !in.per_model, all_atoms = fold && n <= kCidAllAtoms;
     P0("grid_bounds");
-    const uint32_t bb = nb < 1 ? 1 : (nb < kBoundsBlocks ? nb : kBoundsBlocks);
-    hipLaunchKernelGGL(k_bounds, dim3(bb), dim3(256), 0, st, in, ws.partials);
+    const uint32_t nbb = (n + kBoundsThreads - 1u) / kBoundsThreads, bb = nbb < 1 ? 1 : (nbb < kBoundsBlocks ? nbb : kBoundsBlocks);
+    if (!all_atoms) hipLaunchKernelGGL(k_bounds, dim3(bb), dim3(kBoundsThreads), 0, st, in, ws.partials);
     if (in.per_model && n) {
         hipLaunchKernelGGL(k_model_box_init, dim3(65536u * 6u / 256u), dim3(256), 0, st, ws.model_box);
         hipLaunchKernelGGL(k_model_bounds, dim3(nb), dim3(256), 0, st, in, ws.model_box);
     }
-    hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, (const double *)ws.partials, bb, ws.grid, ws.params, cutoff, ws.ncells_cap, n, ws.result,
-                       ws.task_ctr, in.per_model ? (const uint32_t *)ws.model_box : (const uint32_t *)nullptr, ws.model_org);
+    if (!fold) hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, (const double *)ws.partials, bb, ws.grid, ws.params, cutoff, ws.ncells_cap, n, ws.result,
+                                  ws.task_ctr, in.per_model ? (const uint32_t *)ws.model_box : (const uint32_t *)nullptr, ws.model_org);
     P1();
     P0("grid_count");
-    if (n) hipLaunchKernelGGL(k_cellid, dim3((n + kCidThreads * kCidPer - 1u) / (kCidThreads * kCidPer)), dim3(kCidThreads), 0, st, in, (const GridParams *)ws.grid, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count);
+    if (n) {
+        const dim3 cb((n + kCidThreads * kCidPer - 1u) / (kCidThreads * kCidPer));
+#define ARP_LAUNCH_CID(BOX) hipLaunchKernelGGL(k_cellid<BOX>, cb, dim3(kCidThreads), 0, st, in, ws.grid, ws.params, (const double *)ws.partials, bb, cutoff, ws.ncells_cap, \
+                                               ws.result, ws.task_ctr, ws.cell_of_atom, ws.rank_of_atom, ws.cell_count)
+        if (all_atoms) ARP_LAUNCH_CID(2); else if (fold) ARP_LAUNCH_CID(1); else ARP_LAUNCH_CID(0);
+#undef ARP_LAUNCH_CID
+    }
     P1();
     P0("grid_scan");
-    launch_scan<uint32_t, true, false>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, ws.tickets + 1, ws, 0ull, false, st);
+    if (!in.per_model && n <= kScanOneAtoms) hipLaunchKernelGGL(k_scan_one<true>, dim3(1), dim3(kScanOneThreads), 0, st, ws.cell_count, (const uint32_t *)&ws.grid->ncells, ws.cell_start);
+    else launch_scan<uint32_t, true, false>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, ws.tickets + 1, ws, 0ull, false, st);
     P1();
     P0("grid_sort");
     if (ordered) {
@@ -717,35 +736,43 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 // what follows either emit kernel: the deferred probe pass (unless the engine's memo says this input defers nothing) and the hole fix-up
 // patch: the emit kernel wrote the deferred candidates as records with a placeholder kind (k_emit, all candidates): k_patch_deferred decides
 // the kinds in place; otherwise k_pairs_deferred classifies and emits them itself (its blocks add holes of their own)
+// chunk_records == 1: the hole-free sequence of small inputs (k_emit's DIRECT kernels + alloc_direct here): the records lie back to back from
+// position 0, result[2] counts them, and there is nothing to fix up -- the host reads the count and derives the status flags k_fixup would
+// have set (engine.cpp finish_result).  Its probe pass is always k_pairs_deferred: a record's place is only known when its wave flushes.
 static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const EmitTarget &tg, uint32_t nb, hipStream_t st, Profiler *prof, bool skip_deferred, bool patch,
                              uint32_t chunk_records) {
     const uint32_t chunk_shift = chunk_shift_of(chunk_records);
+    const bool direct = chunk_records == 1u;
     if (prof) prof->end(st);
     if (!skip_deferred) {
         if (prof) prof->begin("pairs_deferred", st);
-        if (patch) hipLaunchKernelGGL(k_patch_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.result);
-        else hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result, chunk_shift);
+        const uint32_t db = direct ? 32u : kDeferBlocks;  // (a small input defers a few hundred candidates at most)
+        if (patch && !direct) hipLaunchKernelGGL(k_patch_deferred, dim3(db), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.result);
+        else hipLaunchKernelGGL(k_pairs_deferred, dim3(db), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result, chunk_shift);
         if (prof) prof->end(st);
     }
+    if (direct) return;
     if (prof) prof->begin("pairs_fixup", st);
     hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, (skip_deferred || patch) ? nb : nb + kDeferBlocks,
                        (const GridParams *)ws.grid, tg, ws.result, skip_deferred ? 1u : 0u, chunk_shift);
     if (prof) prof->end(st);
 }
-void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+bool launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
                    bool skip_deferred);
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
-void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+// Returns true when the hole-free sequence of small inputs ran: result[0] and the flags k_fixup sets are then the host's to derive from
+// result[2] (the records) and result[3] (the deferred list's chunks) -- engine.cpp finish_result.
+bool launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
                  bool skip_deferred) {
     if (in.n >= kBigSlots) {  // beyond the 32-bit record offsets of the single-pass kernels: count + ordered fill with inline probes
         launch_count(in, ws, st, prof, capacity, true, contacts_only);
         launch_fill_ordered(in, ws, out, capacity, st, prof, contacts_only);
-        return;
+        return false;
     }
     // The default is k_emit (pairs_emit.inl).  This file's k_pairs<kEmit> -- both exact operands gathered, 8-byte queue entries -- is the
     // one alternative kept: it takes the inputs beyond k_emit's 2^24 slots, and ARP_EMIT_KERNEL=gather selects it for the parity suite.
     static const bool gather = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'g'; }();
-    if (!gather && in.n < (1u << kESlotBits) - 64u) { launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred); return; }
+    if (!gather && in.n < (1u << kESlotBits) - 64u) return launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred);
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t nb = blocks_for(in.n, kEmitBlocks);
     if (prof) prof->begin("pairs_emit", st);
@@ -753,4 +780,5 @@ void launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
                        (const uint32_t *)ws.cell_start, ws.sorted, ws.task_count, (const unsigned long long *)ws.task_base, tg, ws.hole_list,
                        ws.task_ctr, ws.result);
     launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, false, kChunkRecords);
+    return false;
 }

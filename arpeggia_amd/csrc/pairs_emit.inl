@@ -189,6 +189,28 @@ DEVFN void store_batch_general(const Slots &sl, lmask m_valid, uint32_t n_rec, u
     }
 }
 
+// The hole-free sequence of small inputs (k_emit's DIRECT kernels): a wave collects its records in a private LDS buffer and takes the places
+// of a whole buffer at once from the global RECORD counter -- result[2], one returning atomic per flush; what is left at the end of the launch
+// goes out in one flush per block.  The list then has no holes and the sequence no fix-up launch (11 us of a 60 us call); the atomics all hit
+// one address (~11 ns each when they queue up), which is why this stops at the 4-wave kernels: 20 000 atoms are ~1 500 flushes.
+constexpr uint32_t kStageRecords = 512;
+struct StageRef { uint4 *buf; uint32_t n; };  // (n: wave-uniform)
+DEVFN void stage_copy_e(const uint4 *buf, uint32_t n, unsigned long long pos, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
+    wave_lds_fence();  // lanes read records other lanes wrote
+    for (uint32_t k = lane; k < n; k += 64u) {
+        uint4 *d = emit_slot(tg, pos + k, result);
+        if (d) store_record(d, buf[k]);
+    }
+    wave_lds_fence();  // ... before the buffer is written again
+}
+DEVFN void stage_flush_e(StageRef &sg, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(sg.n);
+    if (n == 0u) return;
+    const Slots sl = alloc_direct(&result[2], n, lane);
+    stage_copy_e(sg.buf, n, sl.pos0, tg, result, lane);
+    sg.n = 0u;
+}
+
 // Phase 2 on the 64 queue entries that start at byte `qoff` of the wave's queue (FULL) or on its first `count` < 64 entries (!FULL, qoff = 0):
 // home operands out of LDS, neighbour operands gathered (40 of the 48 bytes of the exact record).  Every lane computes everything -- the
 // lanes beyond count on entry 0 (home lane 0, slot 0: in bounds) -- and only the stores are predicated.
@@ -217,9 +239,12 @@ DEVFN ExactRegs exact_issue_e(const WaveLdsE &w, const Sorted &so, uint32_t qoff
     g.kb = *reinterpret_cast<const unsigned long long *>(gp + 32);
     return g;
 }
+// CHUNK == 1: the hole-free sequence of small inputs -- no block allocator, the batch's records go to the wave's staging buffer (sg) on the
+// general path; a pair a probe has to decide is handed to k_pairs_deferred in both modes (its place is not known before the flush).
 template <bool FULL, bool ONLY, uint32_t CHUNK>
 DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, uint32_t count, uint32_t slot0,
-                          const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits) {
+                          const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits, StageRef &sg) {
+    constexpr bool DIRECT = CHUNK == 1u;
     count = __builtin_amdgcn_readfirstlane(count);
     const uint32_t e = g.e, hl = e >> kESlotBits, nb = e & kESlotMask;
     const u32x4 bxy = g.bxy, bzp = g.bzp;
@@ -258,7 +283,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
     u32x2 a_old = {0u, 0u};
     if (!ONLY) {
         if (__builtin_expect(n_rec == 0u, 0)) return;
-        a_old = alloc_issue_e(bl.alloc_state, n_rec);
+        if (!DIRECT) a_old = alloc_issue_e(bl.alloc_state, n_rec);
     }
     // distance levels: Le against the element pair's bounds {vdw, cov, clash}, Lg against the fixed ones {4.5, 4.0, 3.5}; L = 4 Le + Lg.
     // All candidates (!ONLY): only the van-der-Waals bound on the common path -- a distance below the covalent or the clash bound of ITS
@@ -328,12 +353,12 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
                                      lm_gt_u32_sv(4097u, low - (0x10000000u - 2048u)));
     if (ONLY) {  // the records that stay are known: ask for their places now, the answer is read after the rare paths
         n_rec = lm_count(m_valid & ~m_defer);
-        if (n_rec) a_old = alloc_issue_e(bl.alloc_state, n_rec);
+        if (n_rec && !DIRECT) a_old = alloc_issue_e(bl.alloc_state, n_rec);
     }
     u32x4 rec;
     rec.x = lm_select(m_swap, bzp.w, azp.w); rec.y = lm_select(m_swap, azp.w, bzp.w);
     uint32_t general;  // (wave-uniform, and opaque to the optimiser in both arms: as a bool it comes back as a lane mask + three scalar instructions per use)
-    if (__builtin_expect((m_exact | m_defer | m_close) == 0ull, 1)) {
+    if (!DIRECT && __builtin_expect((m_exact | m_defer | m_close) == 0ull, 1)) {
         rec.z = __float_as_uint((float)y);
         rec.w = kind;
         if (ONLY) { if (n_rec == 0u) return; }
@@ -375,7 +400,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
         asm volatile("s_mov_b32 %0, 1" : "=s"(general));
     }
     if (__builtin_expect(general != 0u, 0)) {  // ---- chunk crossing / refill / scratch / a probe decides: the general placement ----
-        if (ONLY) {
+        if (ONLY || DIRECT) {
             if (m_defer) {  // candidates whose rules need a probe go to the deferred pass (k_pairs_deferred), as global slot pairs
                 const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], (uint32_t)__popcll(m_defer), lane);
                 if (lm_lane(m_defer, lane)) {
@@ -384,8 +409,16 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
                     if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(slot0 + hl, nb); else atomicOr(&result[1], 8ull);
                 }
                 m_valid &= ~m_defer;
+                if (!ONLY) n_rec = lm_count(m_valid);  // (DIRECT, all candidates)
             }
             if (n_rec == 0u) return;
+        }
+        if (DIRECT) {
+            if (sg.n + n_rec > kStageRecords) stage_flush_e(sg, tg, result, lane);
+            rec.w = kind;
+            if (lm_lane(m_valid, lane)) sg.buf[sg.n + lm_rank(m_valid)] = make_uint4(rec.x, rec.y, rec.z, rec.w);
+            sg.n += n_rec;
+            return;
         }
         const Slots sl = alloc_finish<CHUNK>(bl.alloc_state, &result[2], n_rec, lane, u64_of(a_old));
         const uint32_t rank = lm_rank(m_valid);
@@ -409,16 +442,30 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
 // SPLIT: 1, or 4 = a task's five window kinds are shared out over four waves ({0, 1}, {2}, {3}, {4}), or 8 = two waves per kind set on
 // alternate 32-test runs: a small input has few tasks and each is a long chain of dependent round trips, so more waves on a
 // fraction of the chain each is what shortens the launch
-template <int WAVES, int SPLIT, bool ONLY>
-__global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
+// DIRECT (with SPLIT 8, the smallest inputs): no allocation chunks -- a batch takes its places from the global record counter, the list has
+// no holes and the launch sequence no fix-up kernel (alloc_direct, direct_finish in pairs.inl)
+struct StageLdsE { uint4 rec[4][kStageRecords]; uint32_t wave_n[4]; unsigned long long base; };
+struct NoStageLdsE { uint4 rec[1][1]; uint32_t wave_n[1]; unsigned long long base; };
+template <int WAVES, int SPLIT, bool ONLY, bool DIRECT = false>
+__global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
                                                                                            EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     // Inputs that do not fill the chip emit a few thousand records per block, or a few hundred: a 4096-record chunk per block would leave
     // holes as large as the list itself for the fix-up to close.  (Not smaller than this: every chunk costs a returning atomic on the one
     // global counter, ~11 ns each when they queue up -- 256-record chunks made the kernel 2.4x slower on 10^5 atoms and 30 % slower on 2x10^4.)
-    constexpr uint32_t kChunkE = SPLIT == 8 ? kTinyChunkRecords : (SPLIT == 4 ? kSmallChunkRecords : kChunkRecords);
+    // The 4-wave kernels' inputs (DIRECT: below 320 tasks) go without chunks altogether: the records are staged per wave and flushed to places
+    // taken from the global record counter (stage_flush_e): no holes, no fix-up launch.
+    static_assert(!DIRECT || WAVES == 4, "the hole-free sequence is the 4-wave kernels'");
+    constexpr uint32_t kChunkE = DIRECT ? 1u : (SPLIT == 4 ? kSmallChunkRecords : kChunkRecords);
+    static_assert(DIRECT || WAVES == kEWaves, "the 4-wave kernels are DIRECT");
     __shared__ TablesE tb;
     __shared__ WaveLdsE wl[WAVES];
     __shared__ BlockLds bl;
+    __shared__ typename std::conditional<DIRECT, StageLdsE, NoStageLdsE>::type stg;
+    // (the grid and parameter words first: their loads travel together with the table's instead of behind the barrier)
+    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
+    const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
+    const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar, dprm->s_cov_max};
+    const double r2m = gp->r2m;
     load_tables_e(tb, dprm);
     if (threadIdx.x == 0) {
         bl.alloc_state = kAllocEmpty | kChunkE;  // "exhausted": the first allocation fetches a chunk
@@ -427,15 +474,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
-    const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
     const uint32_t probe_bits = in.n_res != 0u ? (1u << 29) : 0u;  // residue tables present: CYS SG pairs in the covalent band get their dihedral probe
-    const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar, dprm->s_cov_max};
-    const double r2m = gp->r2m;
     // chunks that lie wholly inside the caller's buffer: a batch placed in one of them needs no further capacity test (exact_finish_e's fast tail)
     // (and inside its first 2^32 bytes: the fast path addresses with a 32-bit byte offset; what lies beyond takes the general path)
     const uint32_t cap_chunks = (uint32_t)min(tg.capacity >> chunk_shift_of(kChunkE), (unsigned long long)((1u << 28) / kChunkE));
     WaveLdsE &w = wl[wave];
+    StageRef sg{stg.rec[DIRECT ? wave : 0u], 0u};
     // task distribution as in k_pairs: block group (b mod 8) = one XCD = one contiguous eighth of the tasks, static first task per wave
     const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
@@ -566,7 +610,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
                             // (Finishing the batch only after the next compaction rounds -- the gathers in flight meanwhile -- was measured: no
                             // gain, 162 us either way; the compiler then parks the next prefilter run on vmcnt(0) for a register it sees reused.)
                             const ExactRegs g = exact_issue_e<true>(w, so, qb - queue_lds, 64u, lane);
-                            exact_finish_e<true, ONLY, kChunkE>(g, K, tb, w, bl, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);
+                            exact_finish_e<true, ONLY, kChunkE>(g, K, tb, w, bl, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg);
                             compact_rounds_e(mask, tag, qb, queue_lds + 256u);
                         }
                         qbyte = qb;
@@ -578,17 +622,32 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 4) 
         if (qbyte != queue_lds) {  // the home records go with the task: drain
             const uint32_t left = (qbyte - queue_lds) >> 2;
             const ExactRegs g = exact_issue_e<false>(w, so, 0u, left, lane);
-            exact_finish_e<false, ONLY, kChunkE>(g, K, tb, w, bl, left, slot0, tg, cap_chunks, result, lane, wflags, probe_bits);
+            exact_finish_e<false, ONLY, kChunkE>(g, K, tb, w, bl, left, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg);
         }
+        if (g_lo + group_waves >= g_hi) break;  // every task of the group was some wave's static first one (small inputs): no round trip to the counter for nothing
         uint32_t nxt_task = 0;
         if (lane == 0) nxt_task = atomicAdd(ctr, 1u);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);
     }
     emit_epilogue(bl, hole_list + blockIdx.x, tg);
+    if (DIRECT) {  // what the waves still hold goes out together: one returning atomic per block
+        const uint32_t mine = __builtin_amdgcn_readfirstlane(sg.n);
+        if (lane == 0u) stg.wave_n[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            uint32_t total = 0;
+            for (int k = 0; k < WAVES; k++) total += stg.wave_n[k];
+            stg.base = total ? atomicAdd(&result[2], (unsigned long long)total) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long pos = stg.base;
+        for (uint32_t k = 0; k < wave; k++) pos += stg.wave_n[k];
+        stage_copy_e(sg.buf, mine, pos, tg, result, lane);
+    }
 }
 
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
-void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
+bool launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
                    bool skip_deferred) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t tasks = (in.n + 63u) / 64u;
@@ -596,25 +655,29 @@ void launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
     // per kind set), and below 320 tasks the blocks shrink to four waves so that the few tasks reach more CUs.  Thresholds from size sweeps
     // of this kernel (tests/microbench/ab_r3ae.sh .. ab_r3ag.sh, profiles/r03_small_inputs.txt): a task is a chain of dependent round trips,
     // and an input that does not fill the chip has nothing else to hide it behind.
-    const bool shared = tasks < 4608u, narrow = tasks < 320u, eight = tasks < 160u;  // (eight: 6bft's 128 tasks run 3 us faster that way, an S2 cloud of the same size 1.3 us slower)
+    // The 4-wave kernels are the hole-free ones (DIRECT); a pack that small keeps the 12-wave sequence with its fix-up, which is what publishes
+    // the count its members' lists are split by on the device.
+    const bool shared = tasks < 4608u, narrow = tasks < 320u && !in.per_model, eight = narrow && tasks < 160u;  // (eight: 6bft's 128 tasks run 3 us faster that way, an S2 cloud of the same size 1.3 us slower)
+    const bool direct = narrow;
     const uint32_t split = eight ? 8u : (shared ? 4u : 1u);
     const uint32_t per = narrow ? 4u : (uint32_t)kEWaves, cap = narrow ? 1536u : kEBlocks, want = (split * tasks + per - 1u) / per;
     const uint32_t nb = want < 1 ? 1 : (want > cap ? cap : want);
     if (prof) prof->begin("pairs_emit", st);
-#define ARP_LAUNCH_E(W, S, O) hipLaunchKernelGGL((k_emit<W, S, O>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
+#define ARP_LAUNCH_E(W, S, O, ...) hipLaunchKernelGGL((k_emit<W, S, O, ##__VA_ARGS__>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
                                                  (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
     if (contacts_only) {
-        if (eight) ARP_LAUNCH_E(4, 8, true);
-        else if (narrow) ARP_LAUNCH_E(4, 4, true);
+        if (eight) ARP_LAUNCH_E(4, 8, true, true);
+        else if (narrow) ARP_LAUNCH_E(4, 4, true, true);
         else if (shared) ARP_LAUNCH_E(kEWaves, 4, true);
         else ARP_LAUNCH_E(kEWaves, 1, true);
     } else {
-        if (eight) ARP_LAUNCH_E(4, 8, false);
-        else if (narrow) ARP_LAUNCH_E(4, 4, false);
+        if (eight) ARP_LAUNCH_E(4, 8, false, true);
+        else if (narrow) ARP_LAUNCH_E(4, 4, false, true);
         else if (shared) ARP_LAUNCH_E(kEWaves, 4, false);
         else ARP_LAUNCH_E(kEWaves, 1, false);
     }
 #undef ARP_LAUNCH_E
-    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, eight ? kTinyChunkRecords : (shared ? kSmallChunkRecords : kChunkRecords));
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, direct ? 1u : (shared ? kSmallChunkRecords : kChunkRecords));
+    return direct;
 }
 static_assert(kEBlocks + 384u <= kMaxHoles && 1536u + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");

@@ -6,5 +6,6 @@ for atoms in 700 2000 4000 8000 12000 20000 30000 40000 60000 100000 150000 1900
   python3 -c "
 import json
 d=json.load(open('$OUT/$atoms.json'))
-print('%8d atoms  emit %6.1f us  fixup %5.1f  step %7.1f us' % ($atoms, d['roofline']['kernels_ms']['pairs_emit']*1000, d['roofline']['kernels_ms']['pairs_fixup']*1000, d['ms_per_step']*1000))"
+k=d['roofline']['kernels_ms']
+print('%8d atoms  emit %6.1f us  fixup %5.1f  grid %5.1f  step %7.1f us' % ($atoms, k['pairs_emit']*1000, k.get('pairs_fixup', 0.0)*1000, sum(v for n, v in k.items() if n.startswith('grid_'))*1000, d['ms_per_step']*1000))"
 done

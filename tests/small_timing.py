@@ -26,9 +26,13 @@ for name in ("1ubq", "6bft"):
         for _ in range(5):
             ctx.enqueue(atoms, prm, out.data_ptr(), n); ctx.result()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        import time
+        torch.cuda.synchronize()
         e0.record(stream)
+        t0 = time.perf_counter()
         for _ in range(50):
             ctx.enqueue(atoms, prm, out.data_ptr(), n)
+        host = (time.perf_counter() - t0) / 50 * 1e6  # host time of one enqueue (launches + the result copy): the stream cannot run faster than this
         e1.record(stream)
         ctx.result()
         whole = e0.elapsed_time(e1) / 50 * 1e3
@@ -36,4 +40,4 @@ for name in ("1ubq", "6bft"):
         ctx.enqueue(atoms, prm, out.data_ptr(), n); ctx.result()
         prof = {k: round(v * 1e3, 1) for k, v in ctx.profile_read().items()}
         ctx.profile(False)
-        print(f"{name}: {s.n_atoms} atoms, {n} pairs out (contacts_only={only}): {whole:.0f} us per call on the stream; kernels us: {prof}")
+        print(f"{name}: {s.n_atoms} atoms, {n} pairs out (contacts_only={only}): {whole:.0f} us per call on the stream (host side of an enqueue: {host:.0f} us); kernels us: {prof}")

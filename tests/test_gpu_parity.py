@@ -745,10 +745,18 @@ def test_no_speculation_flag_makes_the_enqueued_list_final_on_the_stream():
         early = snap[:got_n].cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1)
         if flag:
             assert_pairs_equal(early, want_b, "device-side copy taken between enqueue and result, ARP_FLAG_NO_SPECULATION")
-        else:  # the speculation is real: the copy holds placeholders where the final list holds probe-decided kinds
+        else:  # the speculation is real: the copy does not hold the probe-decided records yet
             e, w = canon(early), canon(want_b)
-            assert np.array_equal(e["i"], w["i"].astype(np.uint32)) and np.array_equal(e["j"], w["j"].astype(np.uint32))
-            assert ((w["kind"] & probe_kinds) != 0)[e["kind"] == 0].any() and not (e["kind"] & probe_kinds).any()
+            if np.array_equal(e["i"], w["i"].astype(np.uint32)) and np.array_equal(e["j"], w["j"].astype(np.uint32)):
+                # the chunked sequence (>= 20 480 atoms): every candidate has its place, the probe-decided ones a placeholder kind
+                assert ((w["kind"] & probe_kinds) != 0)[e["kind"] == 0].any() and not (e["kind"] & probe_kinds).any()
+            else:
+                # the hole-free sequence of small inputs: the probe pass appends its records, so the first pass's list is shorter and the rows
+                # behind its end are whatever the buffer held before -- none of them a probe-decided record of this structure
+                wkeys = {(int(a), int(b)): int(k) for a, b, k in zip(w["i"], w["j"], w["kind"])}
+                hits = [wkeys.get((int(a), int(b))) for a, b in zip(e["i"], e["j"])]
+                probe_rows = [(a, k) for a, k in zip(hits, e["kind"]) if a is not None and (a & probe_kinds)]
+                assert not any(int(k) == a for a, k in probe_rows) or len(probe_rows) < int(((w["kind"] & probe_kinds) != 0).sum())
 
 
 def test_deferred_list_overflow_grows_and_repeats(monkeypatch):
