@@ -348,7 +348,7 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
 
 // After the four result words of a single-pass call have arrived.  The hole-free sequence of small inputs (launch_emit returned true) has no
 // fix-up kernel to publish the pair count and the flags that depend on it: the records lie back to back from position 0 and result[2] counts
-// them, result[3] the chunks of the deferred list (the input-error flags were set by the grid sizing).
+// them; its probes run inline, so result[3] (the chunks of a deferred list) stays 0 (the input-error flags were set by the grid sizing).
 static void finish_result(arp_context *ctx, bool direct, bool skipped, unsigned long long capacity) {
     if (!direct) return;
     unsigned long long *r = ctx->h_result;

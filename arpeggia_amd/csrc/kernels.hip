@@ -157,7 +157,9 @@ constexpr uint32_t kDeferKind = 0xFFFFFFFFu;  // classify<false>: the pair needs
 
 // (weak) hydrogen bond test of hbond.rs:36-58 / 80-102 for the donor chosen by `donor_is_a`: true iff some hydrogen of the donor's
 // residue satisfies the distance and angle conditions.  Only called for donors whose residue carries hydrogens.
-DEVFN bool hbond_probe(const DevAtoms &in, const LdsParams &prm, bool donor_is_a, const Fat &a, const Fat &b, double min_angle) {
+// (P: LdsParams, or ProbeParamsE of the small-input emit kernels -- anything with the bounds as members)
+template <typename P>
+DEVFN bool hbond_probe(const DevAtoms &in, const P &prm, bool donor_is_a, const Fat &a, const Fat &b, double min_angle) {
     const uint32_t res = in.res_id[donor_is_a ? a.orig : b.orig];
     const uint2 hi = make_uint2(in.res_h_ptr[res], in.res_h_ptr[res + 1]);
     const uint32_t acc_attr = donor_is_a ? b.attr : a.attr;
@@ -170,8 +172,8 @@ DEVFN bool hbond_probe(const DevAtoms &in, const LdsParams &prm, bool donor_is_a
 // the order in which the two donor/acceptor assignments are tried (hbond.rs:125-133: the ligand as donor first) and the
 // argument order of the disulfide dihedral; `swap` says that b is the ligand.  Everything on the common path is
 // straight-line predicate arithmetic; only the rare probes branch (PROBES) or defer the pair (!PROBES).
-template <bool PROBES>
-DEVFN uint32_t classify(const DevAtoms &in, const LdsParams &prm, double s, const Fat &a, const Fat &b, bool swap, unsigned long long *result) {
+template <bool PROBES, typename P = LdsParams>
+DEVFN uint32_t classify(const DevAtoms &in, const P &prm, double s, const Fat &a, const Fat &b, bool swap, unsigned long long *result) {
     const uint32_t aa = a.attr, ab = b.attr, both = aa & ab;
     const uint32_t e = ((aa & ARP_ATTR_ELEM_MASK) << 4) | (ab & ARP_ATTR_ELEM_MASK);  // the radius tables are symmetric
     const double t_clash = prm.s_clash[e], t_cov = prm.s_cov[e], t_vdw = prm.s_vdw[e];

@@ -153,16 +153,15 @@ template <uint32_t CHUNK>
 DEVFN Slots alloc_chunked(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane) {
     return alloc_finish<CHUNK>(state, g_head, n, lane, alloc_issue(state, n, lane));
 }
-// The hole-free sequence of small inputs (k_emit's DIRECT kernels stage their records in LDS and take the places of a whole flush at once; the
-// probe pass behind them allocates per batch): n places straight from the global counter, which then counts RECORDS -- a few hundred
-// returning atomics per call, all on one address (~11 ns each when they queue up), instead of a fix-up launch behind the sequence.
+// The hole-free sequence of small inputs (k_emit's DIRECT kernels stage their records in LDS and take the places of a whole flush at once):
+// n places straight from the global counter, which then counts RECORDS -- a few hundred returning atomics per call, all on one address
+// (~11 ns each when they queue up), instead of a fix-up launch behind the sequence.
 DEVFN Slots alloc_direct(unsigned long long *g_head, uint32_t n, uint32_t lane) {
     unsigned long long p = 0;
     if (lane == 0) p = atomicAdd(g_head, (unsigned long long)n);
     return Slots{wave_first_u64(p), 0ull, n};
 }
 DEVFN Slots alloc_chunked_rt(unsigned long long &state, unsigned long long *g_head, uint32_t n, uint32_t lane, uint32_t shift) {
-    if (shift == 0u) return alloc_direct(g_head, n, lane);  // (wave-uniform: the block's chunk_shift)
     return alloc_finish_rt(state, g_head, n, lane, alloc_issue(state, n, lane), shift);
 }
 
@@ -736,22 +735,20 @@ void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out,
 // what follows either emit kernel: the deferred probe pass (unless the engine's memo says this input defers nothing) and the hole fix-up
 // patch: the emit kernel wrote the deferred candidates as records with a placeholder kind (k_emit, all candidates): k_patch_deferred decides
 // the kinds in place; otherwise k_pairs_deferred classifies and emits them itself (its blocks add holes of their own)
-// chunk_records == 1: the hole-free sequence of small inputs (k_emit's DIRECT kernels + alloc_direct here): the records lie back to back from
-// position 0, result[2] counts them, and there is nothing to fix up -- the host reads the count and derives the status flags k_fixup would
-// have set (engine.cpp finish_result).  Its probe pass is always k_pairs_deferred: a record's place is only known when its wave flushes.
+// chunk_records == 1: the hole-free sequence of small inputs (k_emit's DIRECT kernels): the records lie back to back from position 0,
+// result[2] counts them, the probes ran inline -- nothing follows the emit kernel, and the host derives the count and the status flags
+// k_fixup would have published (engine.cpp finish_result).
 static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const EmitTarget &tg, uint32_t nb, hipStream_t st, Profiler *prof, bool skip_deferred, bool patch,
                              uint32_t chunk_records) {
     const uint32_t chunk_shift = chunk_shift_of(chunk_records);
-    const bool direct = chunk_records == 1u;
     if (prof) prof->end(st);
+    if (chunk_records == 1u) return;
     if (!skip_deferred) {
         if (prof) prof->begin("pairs_deferred", st);
-        const uint32_t db = direct ? 32u : kDeferBlocks;  // (a small input defers a few hundred candidates at most)
-        if (patch && !direct) hipLaunchKernelGGL(k_patch_deferred, dim3(db), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.result);
-        else hipLaunchKernelGGL(k_pairs_deferred, dim3(db), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result, chunk_shift);
+        if (patch) hipLaunchKernelGGL(k_patch_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.result);
+        else hipLaunchKernelGGL(k_pairs_deferred, dim3(kDeferBlocks), dim3(kWavesPerBlock * 64), 0, st, in, (const DevParams *)ws.params, ws.sorted, tg, ws.hole_list + nb, ws.result, chunk_shift);
         if (prof) prof->end(st);
     }
-    if (direct) return;
     if (prof) prof->begin("pairs_fixup", st);
     hipLaunchKernelGGL(k_fixup, dim3(256), dim3(kFixThreads), 0, st, (const ulonglong2 *)ws.hole_list, (skip_deferred || patch) ? nb : nb + kDeferBlocks,
                        (const GridParams *)ws.grid, tg, ws.result, skip_deferred ? 1u : 0u, chunk_shift);

@@ -240,10 +240,14 @@ DEVFN ExactRegs exact_issue_e(const WaveLdsE &w, const Sorted &so, uint32_t qoff
     return g;
 }
 // CHUNK == 1: the hole-free sequence of small inputs -- no block allocator, the batch's records go to the wave's staging buffer (sg) on the
-// general path; a pair a probe has to decide is handed to k_pairs_deferred in both modes (its place is not known before the flush).
+// general path, and a pair a probe has to decide is decided HERE, by the lane that holds it (classify<true>, as k_patch_deferred does per
+// list entry): these kernels run at two waves per SIMD anyway, the probes' registers cost them nothing, and a call without a probe pass is
+// one launch shorter.  pe: the bounds the probes read (DIRECT only).
+struct ProbeParamsE { const double *s_clash, *s_cov, *s_vdw, *s_hacc; double s_ion, s_polar, s_hphob; };
 template <bool FULL, bool ONLY, uint32_t CHUNK>
 DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, uint32_t count, uint32_t slot0,
-                          const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits, StageRef &sg) {
+                          const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits, StageRef &sg,
+                          const DevAtoms &in, const Sorted &so, const ProbeParamsE &pe) {
     constexpr bool DIRECT = CHUNK == 1u;
     count = __builtin_amdgcn_readfirstlane(count);
     const uint32_t e = g.e, hl = e >> kESlotBits, nb = e & kESlotMask;
@@ -400,7 +404,16 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
         asm volatile("s_mov_b32 %0, 1" : "=s"(general));
     }
     if (__builtin_expect(general != 0u, 0)) {  // ---- chunk crossing / refill / scratch / a probe decides: the general placement ----
-        if (ONLY || DIRECT) {
+        if (DIRECT && m_defer) {  // the probes, inline (rare: a donor..acceptor pair of a residue with hydrogens, a CYS SG pair in the covalent band)
+            if (lm_lane(m_defer, lane)) {
+                const Fat a = so.fat[slot0 + hl], b = so.fat[nb];
+                const double s2 = sq_dist(a.x, a.y, a.z, b.x, b.y, b.z);
+                kind = classify<true, ProbeParamsE>(in, pe, s2, a, b, orient(a, b) == 2, result);
+            }
+            if (ONLY) { m_valid &= ~m_defer | lm_lt_u32_sv(0u, kind); n_rec = lm_count(m_valid); }  // a probe-decided pair without a row is dropped like any other
+            m_defer = 0ull;
+        }
+        if (ONLY) {
             if (m_defer) {  // candidates whose rules need a probe go to the deferred pass (k_pairs_deferred), as global slot pairs
                 const Slots ds = alloc_chunked<kDeferChunk>(bl.defer_state, &result[3], (uint32_t)__popcll(m_defer), lane);
                 if (lm_lane(m_defer, lane)) {
@@ -409,7 +422,6 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
                     if (p < tg.defer_cap) tg.defer_list[p] = make_uint2(slot0 + hl, nb); else atomicOr(&result[1], 8ull);
                 }
                 m_valid &= ~m_defer;
-                if (!ONLY) n_rec = lm_count(m_valid);  // (DIRECT, all candidates)
             }
             if (n_rec == 0u) return;
         }
@@ -480,6 +492,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     const uint32_t cap_chunks = (uint32_t)min(tg.capacity >> chunk_shift_of(kChunkE), (unsigned long long)((1u << 28) / kChunkE));
     WaveLdsE &w = wl[wave];
     StageRef sg{stg.rec[DIRECT ? wave : 0u], 0u};
+    const ProbeParamsE pe{tb.s_clash, tb.s_cov, tb.s_vdw, dprm->s_hacc, K.s_ion, K.s_polar, K.s_hphob};
     // task distribution as in k_pairs: block group (b mod 8) = one XCD = one contiguous eighth of the tasks, static first task per wave
     const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
@@ -610,7 +623,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
                             // (Finishing the batch only after the next compaction rounds -- the gathers in flight meanwhile -- was measured: no
                             // gain, 162 us either way; the compiler then parks the next prefilter run on vmcnt(0) for a register it sees reused.)
                             const ExactRegs g = exact_issue_e<true>(w, so, qb - queue_lds, 64u, lane);
-                            exact_finish_e<true, ONLY, kChunkE>(g, K, tb, w, bl, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg);
+                            exact_finish_e<true, ONLY, kChunkE>(g, K, tb, w, bl, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg, in, so, pe);
                             compact_rounds_e(mask, tag, qb, queue_lds + 256u);
                         }
                         qbyte = qb;
@@ -622,7 +635,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
         if (qbyte != queue_lds) {  // the home records go with the task: drain
             const uint32_t left = (qbyte - queue_lds) >> 2;
             const ExactRegs g = exact_issue_e<false>(w, so, 0u, left, lane);
-            exact_finish_e<false, ONLY, kChunkE>(g, K, tb, w, bl, left, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg);
+            exact_finish_e<false, ONLY, kChunkE>(g, K, tb, w, bl, left, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg, in, so, pe);
         }
         if (g_lo + group_waves >= g_hi) break;  // every task of the group was some wave's static first one (small inputs): no round trip to the counter for nothing
         uint32_t nxt_task = 0;
