@@ -330,7 +330,7 @@ struct TableCache {
     std::string rings_groups; bool have_rings_dev = false;   // the ring entities as the device wants them, for this chain-group spec
     std::vector<RingEnt> rings_dev;
     DevStructure dev;
-    ~TableCache() { join_book(); if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); } }
+    ~TableCache() { join_book(); if (dev.block) { (void)hipSetDevice(dev.device); (void)hipFree(dev.block); if (dev.derived) (void)hipFree(dev.derived); if (dev.rings_block) (void)hipFree(dev.rings_block); } }
 };
 void free_table_cache(void *p) { delete (TableCache *)p; }
 uint32_t be32(const char *p) { return ((uint32_t)(unsigned char)p[0] << 24) | ((uint32_t)(unsigned char)p[1] << 16) | ((uint32_t)(unsigned char)p[2] << 8) | (uint32_t)(unsigned char)p[3]; }
@@ -506,7 +506,7 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
     TBL_HIP(hipSetDevice(device));
     const uint64_t n = s->n, nr = s->residues.size(), nh = s->res_h_idx.size(), nm = c->model_rank.size();
     if (!d.block || d.device != device) {
-        if (d.block) { (void)hipSetDevice(d.device); (void)hipFree(d.block); if (d.derived) (void)hipFree(d.derived); (void)hipSetDevice(device); d.block = nullptr; d.derived = nullptr; }
+        if (d.block) { (void)hipSetDevice(d.device); (void)hipFree(d.block); if (d.derived) (void)hipFree(d.derived); if (d.rings_block) (void)hipFree(d.rings_block); (void)hipSetDevice(device); d.block = nullptr; d.derived = nullptr; d.rings_block = nullptr; d.rings_cap = 0; d.rings_host.clear(); }
         struct Seg { const void *src; uint64_t bytes; void **dst; };
         Seg seg[] = {{s->x.data(), n * 8, (void **)&d.x}, {s->y.data(), n * 8, (void **)&d.y}, {s->z.data(), n * 8, (void **)&d.z},
                      {s->attr.data(), n * 4, (void **)&d.attr}, {s->res_ord.data(), n * 4, (void **)&d.res_ord}, {s->res_id.data(), n * 4, (void **)&d.res_id},

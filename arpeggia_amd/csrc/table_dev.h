@@ -45,6 +45,9 @@ struct DevStructure {
     uint32_t n_chains = 0, n_models = 0;  // distinct chain ids / models of the structure (widths of the sort keys)
     bool any_icode = false;              // some atom carries an insertion code (otherwise that sort pass is skipped)
     std::string attr_groups;             // the chain groups the resident attr words were built for
+    char *rings_block = nullptr;         // the ring entities {RingEnt[], EntKey[]} on the device; sent again when they differ from rings_host (table_dev.hip)
+    uint64_t rings_cap = 0;
+    std::vector<char> rings_host;
 };
 
 struct TableRow { uint32_t from_ent, to_ent; float distance; int32_t interaction; };   // entity = atom index, or n_atoms + ring index

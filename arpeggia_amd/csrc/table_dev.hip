@@ -133,14 +133,22 @@ __device__ inline void append_row(uint4 *rows, uint32_t *n_rows, uint32_t cap, u
 // R*-tree of all atoms around every ring centre; here one wave per ring visits the cells its search sphere touches -- a handful of
 // x-contiguous slot runs of the cell-sorted records the engine left in its workspace (Fat: coordinates, attribute word, residue ordinal,
 // chain, original index) -- and only positively ionizable atoms by RESIDUE name (aromatic.rs:18) go on to the plane arithmetic.
+// Two chores ride along (each was a launch of its own, 4-5 us on a table that takes 200): every ring's packed {centre, model serial | flags}
+// record for k_ring_ring's sweep, and -- so that ONE 16-byte read-back brings the host both row counts -- the atom-row total of the offset
+// scan that ran before this kernel goes next to the ring-row counter (counters[3]).
+struct RingPoint { double c[3]; int32_t model_serial; uint32_t flags; };
 __global__ __launch_bounds__(64) void k_ring_atom(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, uint32_t n_atoms, const int32_t *model_serial_of,
                                                   const GridParams *gp, const uint32_t *cell_start, const Fat *fat, double radius, uint4 *rows, uint32_t *n_rows,
-                                                  uint32_t cap) {
+                                                  uint32_t cap, RingPoint *pts, const uint32_t *atom_rows_total) {
     const uint32_t e = blockIdx.x;
     if (e >= n_rings) return;
     const RingEnt ring = rings[e];
-    if (!(ring.flags & 4u)) return;
     const PlaneD pl = ring_planes[ring.src_res];
+    if (threadIdx.x == 0u) {
+        pts[e] = RingPoint{{pl.c[0], pl.c[1], pl.c[2]}, ring.model_serial, ring.flags};
+        if (e == 0u && atom_rows_total) n_rows[3] = *atom_rows_total;
+    }
+    if (!(ring.flags & 4u)) return;
     const ResKeyD rk{ring.model_serial, ring.chain_rank, ring.ord, (ring.flags & 1u) != 0u, (ring.flags & 2u) != 0u};
     const GridParams g = *gp;
     if (g.model_org || g.n_heavy == 0u) return;  // (a packed batch's grid never reaches the table path)
@@ -182,14 +190,6 @@ __global__ __launch_bounds__(64) void k_ring_atom(uint32_t n_rings, const RingEn
 // get_ring_ring_contacts (complex.rs:354-405) + find_pi_pi (aromatic.rs:33-64): ordered ring pairs, k1 in the ligand set, k2 in
 // the receptor set.  The sweep over the other rings reads a packed {centre, model serial | flags} record per ring (32 bytes, coalesced);
 // the plane and the ring entry are gathered only for the few rings within 6 A.
-struct RingPoint { double c[3]; int32_t model_serial; uint32_t flags; };
-__global__ __launch_bounds__(256) void k_ring_points(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, RingPoint *pts) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_rings) return;
-    const RingEnt k = rings[e];
-    const PlaneD p = ring_planes[k.src_res];
-    pts[e] = RingPoint{{p.c[0], p.c[1], p.c[2]}, k.model_serial, k.flags};
-}
 __global__ __launch_bounds__(256) void k_ring_ring(uint32_t n_rings, const RingEnt *rings, const PlaneD *ring_planes, const RingPoint *pts, uint32_t n_atoms, uint4 *rows,
                                                    uint32_t *n_rows, uint32_t cap) {
     const uint32_t e1 = blockIdx.x;
@@ -218,13 +218,21 @@ __global__ __launch_bounds__(256) void k_ring_ring(uint32_t n_rings, const RingE
 }
 
 // atom-atom rows: one per set bit of the pair's kind word (complex.rs:217-296), in pair order
-__global__ __launch_bounds__(256) void k_count_bits(const arp_pair *pairs, uint32_t n_pairs, uint32_t *bits) {
+// (launched over n_pairs + 1 items: the extra one is the scan's closing zero; the first 64 threads clear the call's counters -- two memsets less)
+__global__ __launch_bounds__(256) void k_count_bits(const arp_pair *pairs, uint32_t n_pairs, uint32_t *bits, uint32_t *counters) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < 64u) counters[p] = 0u;
     if (p < n_pairs) bits[p] = (uint32_t)__popc(pairs[p].kind);
+    else if (p == n_pairs) bits[p] = 0u;
 }
-__global__ __launch_bounds__(256) void k_expand_rows(const arp_pair *pairs, uint32_t n_pairs, const uint32_t *first, uint4 *rows, uint32_t cap) {
+// (items n_pairs .. n_pairs + n_ring_rows - 1 move the ring kernels' rows behind the atom rows)
+__global__ __launch_bounds__(256) void k_expand_rows(const arp_pair *pairs, uint32_t n_pairs, const uint32_t *first, uint4 *rows, uint32_t cap, const uint4 *ring_rows,
+                                                     uint32_t n_ring_rows, uint32_t n_atom_rows) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
+    if (p >= n_pairs) {
+        if (p - n_pairs < n_ring_rows && n_atom_rows + (p - n_pairs) < cap) rows[n_atom_rows + (p - n_pairs)] = ring_rows[p - n_pairs];
+        return;
+    }
     const arp_pair q = pairs[p];
     uint32_t o = first[p];
     for (uint32_t b = q.kind; b; b &= b - 1u, ++o)
@@ -295,9 +303,10 @@ struct SortTables {
 };
 __global__ __launch_bounds__(256) void k_row_key(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, int pass, uint32_t n_atoms, const EntKey *atom_keys,
                                                  const EntKey *ring_keys, const uint32_t *ent_rank, const uint32_t *chain_rank, const uint32_t *model, const uint32_t *model_rank,
-                                                 const RingEnt *rings, SortTables tb, unsigned long long *key) {
+                                                 const RingEnt *rings, SortTables tb, unsigned long long *key, uint32_t *perm_init) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_rows) return;
+    if (perm_init) perm_init[p] = p;  // the first pass starts from the identity: written here (perm == nullptr), not by a launch of its own
     const uint4 r = rows[perm ? perm[p] : p];
     auto ins_of = [&](uint32_t e) { return e < n_atoms ? atom_keys[e].icode : ring_keys[e - n_atoms].icode; };
     auto chain_of = [&](uint32_t e) { return e < n_atoms ? (uint32_t)chain_rank[e] : rings[e - n_atoms].chain_rank; };
@@ -363,9 +372,11 @@ __global__ __launch_bounds__(256) void k_tie_fix(uint32_t n_rows, const uint4 *r
 
 // final order + collect_sc_stats (complex.rs:137-174): res1 = ligand residue, res2 = receptor residue
 __global__ __launch_bounds__(256) void k_finish_rows(uint32_t n_rows, const uint4 *rows, const uint32_t *perm, uint32_t n_atoms, const uint32_t *atom_sc_src, const RingEnt *rings,
-                                                     const PlaneD *sc_planes, const uint8_t *valid, uint4 *out_rows, float4 *out_sc) {
+                                                     const PlaneD *sc_planes, const uint8_t *valid, uint4 *out_rows, float4 *out_sc, const uint32_t *tie_overflow,
+                                                     uint32_t *flag_out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_rows) return;
+    if (p == 0u) *flag_out = *tie_overflow;  // (k_tie_fix ran before: the flag travels with the rows, in the one copy that fetches them)
     const uint4 r = rows[perm[p]];
     out_rows[p] = r;
     const uint32_t s1 = r.x < n_atoms ? atom_sc_src[r.x] : rings[r.x - n_atoms].sc_src, s2 = r.y < n_atoms ? atom_sc_src[r.y] : rings[r.y - n_atoms].sc_src;
@@ -438,9 +449,10 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
                                              (uint32_t *)nullptr, (int)n_ent, 0, 64);
     const uint64_t ring_rows_cap = 64 * n_rings + 1024;  // each ring meets a handful of cations / rings; checked below
     uint64_t need = 2 * al(nr * sizeof(PlaneD)) + al(nr) + al(n_rings * sizeof(RingEnt)) + al(n_rings * sizeof(EntKey)) + al(n_rings * 32) + 4096 + al((n_pairs + 1) * 4) * 2 +
-                    al(std::max(cub_scan, cub_sort_ent)) + al(n_ent * 8) * 2 + al(n_ent * 4) * 4;
+                    al(std::max(cub_scan, cub_sort_ent)) + al(n_ent * 8) * 2 + al(n_ent * 4) * 4 + al(ring_rows_cap * 16);
     char *dev = nullptr, *pin = nullptr;
-    arp_status s = context_scratch(ctx, 0, need, al(n_rings * (sizeof(RingEnt) + sizeof(EntKey))) + 4096, &dev, &pin);
+    const uint64_t pin_bytes = al(n_rings * sizeof(RingEnt)) + al(n_rings * sizeof(EntKey)) + 4096;
+    arp_status s = context_scratch(ctx, 0, need, pin_bytes, &dev, &pin);
     if (s != ARP_OK) return s;
     Bump b{dev, 0, need};
     // planes and entity ranks depend on the structure alone: computed by the first call, kept with the resident copy
@@ -455,30 +467,41 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
     }
     PlaneD *ring_pl = (PlaneD *)ds.ring_pl, *sc_pl = (PlaneD *)ds.sc_pl;
     uint8_t *valid = ds.pl_valid;
-    RingEnt *d_rings = b.take<RingEnt>(n_rings);
-    EntKey *d_ring_keys = b.take<EntKey>(n_rings);
+    // the ring entities live on the device with the structure; they are sent again when they change (the chain groups are part of them)
+    RingEnt *d_rings = nullptr;
+    EntKey *d_ring_keys = nullptr;
+    if (n_rings) {
+        const uint64_t rb = n_rings * sizeof(RingEnt), kb = n_rings * sizeof(EntKey), tot = al(rb) + kb;
+        bool send = ds.rings_host.size() != tot || memcmp(ds.rings_host.data(), rings.data(), rb) != 0 || memcmp(ds.rings_host.data() + al(rb), ring_keys.data(), kb) != 0;
+        if (!ds.rings_block || ds.rings_cap < tot) {
+            if (ds.rings_block) { (void)hipStreamSynchronize(st); (void)hipFree(ds.rings_block); ds.rings_block = nullptr; }
+            TRY_HIP(hipMalloc((void **)&ds.rings_block, tot + tot / 4));
+            ds.rings_cap = tot + tot / 4; send = true;
+        }
+        d_rings = reinterpret_cast<RingEnt *>(ds.rings_block); d_ring_keys = reinterpret_cast<EntKey *>(ds.rings_block + al(rb));
+        if (send) {
+            ds.rings_host.assign(tot, 0);
+            memcpy(ds.rings_host.data(), rings.data(), rb); memcpy(ds.rings_host.data() + al(rb), ring_keys.data(), kb);
+            memcpy(pin, ds.rings_host.data(), tot);
+            TRY_HIP(hipMemcpyAsync(ds.rings_block, pin, tot, hipMemcpyHostToDevice, st));
+        }
+    }
     RingPoint *ring_pts = b.take<RingPoint>(n_rings);
     uint32_t *counters = b.take<uint32_t>(64);  // [0] rows, [1] tie runs too long for k_tie_fix, [2] largest entity rank
     uint32_t *bits = b.take<uint32_t>(n_pairs + 1), *first = b.take<uint32_t>(n_pairs + 1);
     char *cub_tmp = b.take<char>(std::max(cub_scan, cub_sort_ent));
     unsigned long long *ek0 = b.take<unsigned long long>(n_ent), *ek1 = b.take<unsigned long long>(n_ent);
     uint32_t *eid0 = b.take<uint32_t>(n_ent), *eid1 = b.take<uint32_t>(n_ent), *eflag = b.take<uint32_t>(n_ent), *ent_rank = ds.ent_rank;
+    uint4 *ring_rows = b.take<uint4>(ring_rows_cap);  // the ring kernels' rows, until the row buffers exist (they are sized by BOTH row counts: one read-back)
+    volatile uint32_t *counts_host = reinterpret_cast<volatile uint32_t *>(pin + pin_bytes - 64);  // pinned landing of that read-back
 
-    if (n_rings) {
-        memcpy(pin, rings.data(), n_rings * sizeof(RingEnt));
-        memcpy(pin + al(n_rings * sizeof(RingEnt)), ring_keys.data(), n_rings * sizeof(EntKey));
-        TRY_HIP(hipMemcpyAsync(d_rings, pin, n_rings * sizeof(RingEnt), hipMemcpyHostToDevice, st));
-        TRY_HIP(hipMemcpyAsync(d_ring_keys, pin + al(n_rings * sizeof(RingEnt)), n_rings * sizeof(EntKey), hipMemcpyHostToDevice, st));
-    }
-    TRY_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(uint32_t), st));
     auto grid = [](uint64_t items, uint32_t block) { return dim3((uint32_t)std::max<uint64_t>(1, (items + block - 1) / block)); };
     // f1: plane fits
     if (nr && derive) hipLaunchKernelGGL(k_fit_planes, grid(nr, 128), dim3(128), 0, st, (uint32_t)nr, (const uint32_t *)ds.res_atom_ptr, (const uint32_t *)ds.res_atom_idx,
                                (const uint8_t *)ds.plane_bits, (const double *)ds.x, (const double *)ds.y, (const double *)ds.z, ring_pl, sc_pl, valid);
     // atom-atom rows: bit count -> offsets -> rows (after the total is known)
+    hipLaunchKernelGGL(k_count_bits, grid(n_pairs + 1, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, bits, counters);  // (also clears the counters)
     if (n_pairs) {
-        hipLaunchKernelGGL(k_count_bits, grid(n_pairs, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, bits);
-        TRY_HIP(hipMemsetAsync(bits + n_pairs, 0, sizeof(uint32_t), st));
         size_t tmp = cub_scan;
         TRY_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, (const uint32_t *)bits, first, (int)n_pairs + 1, st));
     }
@@ -519,43 +542,47 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         ds.max_ent_rank = max_rank;
     }
     lap("planes+bits+ranks");
-    // how many atom rows?  (one small read-back: the row buffers are sized by it)
-    uint32_t n_atom_rows = 0;
-    if (n_pairs) TRY_HIP(hipMemcpyAsync(&n_atom_rows, first + n_pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    TRY_HIP(hipStreamSynchronize(st));
-    const uint64_t rows_cap = (uint64_t)n_atom_rows + ring_rows_cap;
-    size_t cub_sort_rows = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort_rows, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
-                                             (uint32_t *)nullptr, (int)rows_cap, 0, 64);
-    const uint64_t need2 = al(rows_cap * 16) * 3 + al(rows_cap * 8) * 2 + al(rows_cap * 4) * 2 + al(cub_sort_rows) + 4096;
-    char *dev2 = nullptr, *pin2 = nullptr;  // the row-sized buffers live in a scratch slot of their own: the first one must not move
-    if ((s = context_scratch(ctx, 1, need2, 2 * al(rows_cap * 16) + 4096, &dev2, &pin2)) != ARP_OK) return s;
-    b = Bump{dev2, 0, need2};
-    pin = pin2;
-    lap("scratch");
-    uint4 *rows = b.take<uint4>(rows_cap), *out_rows = b.take<uint4>(rows_cap);
-    float4 *out_sc = b.take<float4>(rows_cap);
-    unsigned long long *rk0 = b.take<unsigned long long>(rows_cap), *rk1 = b.take<unsigned long long>(rows_cap);
-    uint32_t *perm0 = b.take<uint32_t>(rows_cap), *perm1 = b.take<uint32_t>(rows_cap);
-    char *cub_tmp2 = b.take<char>(cub_sort_rows);
-    if (n_pairs) hipLaunchKernelGGL(k_expand_rows, grid(n_pairs, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, (const uint32_t *)first, rows, (uint32_t)rows_cap);
-    TRY_HIP(hipMemcpyAsync(counters, first + (n_pairs ? n_pairs : 0), n_pairs ? sizeof(uint32_t) : 0, hipMemcpyDeviceToDevice, st));
-    // f1: ring rows, appended behind the atom rows
+    // f1: the ring rows, into a buffer of their own (their number is bounded up front) -- so that the ONE read-back below brings both the
+    // atom-row and the ring-row count and the row buffers are sized exactly, without a second wait for the device.
     if (n_rings) {
         // the cell list of the pair pass that has just run on this context, on these very arrays
         const GridParams *gridp = nullptr; const uint32_t *cell_start = nullptr; const Fat *fat = nullptr;
         if (!context_grid(ctx, ds.x, ds.n, &gridp, &cell_start, &fat)) { set_error("internal error: the context holds no cell list of this structure"); return ARP_ERR_HIP; }
         hipLaunchKernelGGL(k_ring_atom, dim3((uint32_t)n_rings), dim3(64), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (uint32_t)n,
-                           (const int32_t *)ds.model_serial_of, gridp, cell_start, fat, dist_cutoff, rows, counters, (uint32_t)rows_cap);
-        hipLaunchKernelGGL(k_ring_points, grid(n_rings, 256), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, ring_pts);
-        hipLaunchKernelGGL(k_ring_ring, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (const RingPoint *)ring_pts, (uint32_t)n, rows, counters,
-                           (uint32_t)rows_cap);
+                           (const int32_t *)ds.model_serial_of, gridp, cell_start, fat, dist_cutoff, ring_rows, counters, (uint32_t)ring_rows_cap, ring_pts,
+                           n_pairs ? (const uint32_t *)(first + n_pairs) : (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_ring_ring, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (const RingPoint *)ring_pts, (uint32_t)n, ring_rows,
+                           counters, (uint32_t)ring_rows_cap);
     }
-    uint32_t n_rows = 0;
-    TRY_HIP(hipMemcpyAsync(&n_rows, counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    // how many rows?  (one small read-back: the row buffers are sized by it)
+    counts_host[0] = counts_host[3] = 0u;
+    if (n_rings) TRY_HIP(hipMemcpyAsync((void *)counts_host, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    else if (n_pairs) TRY_HIP(hipMemcpyAsync((void *)(counts_host + 3), first + n_pairs, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     TRY_HIP(hipStreamSynchronize(st));
-    if (n_rows > rows_cap) { set_error("internal error: more ring rows than reserved (%u > %llu)", n_rows, (unsigned long long)rows_cap); return ARP_ERR_HIP; }
-    lap("rows");
+    const uint32_t n_ring_rows = counts_host[0], n_atom_rows = counts_host[3];
+    if (n_ring_rows > ring_rows_cap) { set_error("internal error: more ring rows than reserved (%u > %llu)", n_ring_rows, (unsigned long long)ring_rows_cap); return ARP_ERR_HIP; }
+    const uint32_t n_rows = n_atom_rows + n_ring_rows;
+    const uint64_t rows_cap = std::max<uint64_t>(n_rows, 1);
+    size_t cub_sort_rows = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort_rows, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (int)rows_cap, 0, 64);
+    const uint64_t need2 = al(rows_cap * 16) + al(rows_cap * 32 + 256) + al(rows_cap * 8) * 2 + al(rows_cap * 4) * 2 + al(cub_sort_rows) + 4096;
+    char *dev2 = nullptr, *pin2 = nullptr;  // the row-sized buffers live in a scratch slot of their own: the first one must not move
+    if ((s = context_scratch(ctx, 1, need2, 2 * al(rows_cap * 16) + 4096, &dev2, &pin2)) != ARP_OK) return s;
+    b = Bump{dev2, 0, need2};
+    pin = pin2;
+    lap("ring rows + scratch");
+    // the finished table in ONE device block {rows, sc values, the tie-overflow word}: one copy fetches it
+    uint4 *rows = b.take<uint4>(rows_cap);
+    char *out_all = b.take<char>(rows_cap * 32 + 256);
+    uint4 *out_rows = reinterpret_cast<uint4 *>(out_all);
+    float4 *out_sc = reinterpret_cast<float4 *>(out_all + (size_t)n_rows * 16);
+    uint32_t *out_flag = reinterpret_cast<uint32_t *>(out_all + (size_t)n_rows * 32);
+    unsigned long long *rk0 = b.take<unsigned long long>(rows_cap), *rk1 = b.take<unsigned long long>(rows_cap);
+    uint32_t *perm0 = b.take<uint32_t>(rows_cap), *perm1 = b.take<uint32_t>(rows_cap);
+    char *cub_tmp2 = b.take<char>(cub_sort_rows);
+    if (n_pairs + n_ring_rows) hipLaunchKernelGGL(k_expand_rows, grid(n_pairs + n_ring_rows, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, (const uint32_t *)first, rows,
+                                                  (uint32_t)rows_cap, (const uint4 *)ring_rows, n_ring_rows, n_atom_rows);  // (the ring rows behind the atom rows)
     SortTables tb{};
     {
         int o[ARP_N_INTERACTIONS];
@@ -569,7 +596,6 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
     auto width = [](uint64_t v) { uint32_t b = 1; while (b < 32 && (1ull << b) < v) b++; return b; };  // bits that hold 0 .. v-1
     tb.rank_bits = width((uint64_t)ds.max_ent_rank + 1); tb.chain_bits = width(std::max<uint64_t>(ds.n_chains, 1));
     auto sort_and_finish = [&](bool long_way) -> arp_status {
-        hipLaunchKernelGGL(k_iota, grid(n_rows, 256), dim3(256), 0, st, n_rows, perm0);
         const uint32_t model_bits = width(std::max<uint64_t>(ds.n_models, 1)), top = model_bits + 2 * tb.chain_bits;
         int plan[5], end_bit[5], n_pass = 0;
         if (long_way) {
@@ -585,9 +611,9 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         uint32_t *pin_ = perm0, *pout = perm1;
         for (int q = 0; q < n_pass; q++) {
             const int pass = plan[q];
-            hipLaunchKernelGGL(k_row_key, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, pass, (uint32_t)n, (const EntKey *)ds.ent_key,
-                               (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint32_t *)ds.chain_rank, (const uint32_t *)ds.model, (const uint32_t *)ds.model_rank,
-                               (const RingEnt *)d_rings, tb, rk0);
+            hipLaunchKernelGGL(k_row_key, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, q ? (const uint32_t *)pin_ : (const uint32_t *)nullptr, pass, (uint32_t)n,
+                               (const EntKey *)ds.ent_key, (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank, (const uint32_t *)ds.chain_rank, (const uint32_t *)ds.model,
+                               (const uint32_t *)ds.model_rank, (const RingEnt *)d_rings, tb, rk0, q ? (uint32_t *)nullptr : pin_);
             size_t tmp = cub_sort_rows;
             TRY_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp2, tmp, (const unsigned long long *)rk0, rk1, (const uint32_t *)pin_, pout, (int)n_rows, 0, end_bit[q], st));
             std::swap(pin_, pout);
@@ -600,50 +626,40 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
             std::swap(pin_, pout);
         }
         hipLaunchKernelGGL(k_finish_rows, grid(n_rows, 256), dim3(256), 0, st, n_rows, (const uint4 *)rows, (const uint32_t *)pin_, (uint32_t)n, (const uint32_t *)ds.atom_sc_src,
-                           (const RingEnt *)d_rings, (const PlaneD *)sc_pl, (const uint8_t *)valid, out_rows, out_sc);
+                           (const RingEnt *)d_rings, (const PlaneD *)sc_pl, (const uint8_t *)valid, out_rows, out_sc, (const uint32_t *)(counters + 1), out_flag);
         TRY_HIP(hipGetLastError());
         return ARP_OK;
     };
-    uint32_t *tie_overflow = reinterpret_cast<uint32_t *>(pin + 2 * al(rows_cap * 16));  // (pinned, behind the landing area: read back with the rows)
-    *tie_overflow = 0u;
-    if (n_rows) {
-        if ((s = sort_and_finish(false)) != ARP_OK) return s;
-        TRY_HIP(hipMemcpyAsync(tie_overflow, counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        lap("sort+finish");
-    }
-    // Rows and sc values come back in ONE copy each.  A large table lands in a pooled pinned block that the table object then owns (the
+    if (n_rows && (s = sort_and_finish(false)) != ARP_OK) return s;
+    lap("sort+finish");
+    // Rows, sc values and the tie flag come back in ONE copy.  A large table lands in a pooled pinned block that the table object then owns (the
     // Arrow export and the column accessors read it in place); a small one goes through the context's landing buffer into plain arrays.
     out->n = n_rows;
-    const size_t row_bytes = (size_t)n_rows * 16;
-    char *heap = nullptr;
+    const size_t row_bytes = (size_t)n_rows * 16, all_bytes = 2 * row_bytes + 16;
+    char *heap = nullptr, *landing = nullptr;
     if (row_bytes >= (1u << 20)) {
-        out->owner = pinned_block(2 * al(row_bytes));
+        out->owner = pinned_block(all_bytes + 256);
         if (!out->owner) { set_error("out of pinned host memory for the table"); return ARP_ERR_OOM; }
-        out->rows = reinterpret_cast<TableRow *>(out->owner.get());
-        out->sc = reinterpret_cast<TableSc *>(out->owner.get() + al(row_bytes));
+        landing = out->owner.get();
     } else {
-        heap = (char *)malloc(2 * al(row_bytes) + 64);
+        heap = (char *)malloc(all_bytes + 64);
         if (!heap) { set_error("out of host memory"); return ARP_ERR_OOM; }
         out->owner = std::shared_ptr<char>(heap, [](char *q) { free(q); });
-        out->rows = reinterpret_cast<TableRow *>(heap);
-        out->sc = reinterpret_cast<TableSc *>(heap + al(row_bytes));
+        landing = pin;
     }
+    out->rows = reinterpret_cast<TableRow *>(heap ? heap : landing);
+    out->sc = reinterpret_cast<TableSc *>((heap ? heap : landing) + row_bytes);
+    uint32_t tie_overflow = 0u;
     auto fetch = [&]() -> arp_status {
-        if (!heap) {
-            TRY_HIP(hipMemcpyAsync(out->rows, out_rows, row_bytes, hipMemcpyDeviceToHost, st));
-            TRY_HIP(hipMemcpyAsync(out->sc, out_sc, row_bytes, hipMemcpyDeviceToHost, st));
-            TRY_HIP(hipStreamSynchronize(st));
-        } else if (n_rows) {
-            TRY_HIP(hipMemcpyAsync(pin, out_rows, row_bytes, hipMemcpyDeviceToHost, st));
-            TRY_HIP(hipMemcpyAsync(pin + al((uint64_t)rows_cap * 16), out_sc, row_bytes, hipMemcpyDeviceToHost, st));
-            TRY_HIP(hipStreamSynchronize(st));
-            memcpy(heap, pin, row_bytes);
-            memcpy(heap + al(row_bytes), pin + al((uint64_t)rows_cap * 16), row_bytes);
-        }
+        if (!n_rows) return ARP_OK;
+        TRY_HIP(hipMemcpyAsync(landing, out_all, all_bytes, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipStreamSynchronize(st));
+        memcpy(&tie_overflow, landing + 2 * row_bytes, sizeof tie_overflow);
+        if (heap) memcpy(heap, landing, 2 * row_bytes);
         return ARP_OK;
     };
     if ((s = fetch()) != ARP_OK) return s;
-    if (*tie_overflow) {  // a run of more than kTieRun rows with the same ten keys: sort again with the tie-breaking keys as passes of their own
+    if (tie_overflow) {  // a run of more than kTieRun rows with the same ten keys: sort again with the tie-breaking keys as passes of their own
         if ((s = sort_and_finish(true)) != ARP_OK || (s = fetch()) != ARP_OK) return s;
     }
     lap("unpack");

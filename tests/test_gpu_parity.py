@@ -317,6 +317,14 @@ def test_sparse_huge_extent_and_large_coordinates(ctx):
     got, want = run_both(ctx, prod, orc)
     assert len(want) > 1000
     assert_pairs_equal(got, want)
+    # 30 000 atoms in 200 far-apart blobs: the grid takes all the cells the workspace has (a few hundred thousand), several times what the
+    # one-block cell scan holds in its registers per pass (grid.inl k_scan_one: 65 536) -- the launcher picked it by the atom count
+    offs = rng.uniform(-5000, 5000, size=(200, 3))
+    blobs = np.concatenate([rng.uniform(0, 14, size=(150, 3)) + o for o in offs])
+    prod, orc = _both_from(_mini(np.round(blobs, 3)))
+    got, want = run_both(ctx, prod, orc)
+    assert len(want) > 100000
+    assert_pairs_equal(got, want)
 
 
 def test_bad_inputs_are_errors(ctx):
