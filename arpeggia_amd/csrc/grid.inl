@@ -280,7 +280,9 @@ constexpr uint32_t kCidThreads = 256, kCidPer = 4, kCidTable = 2048;
 // BOX: where the grid parameters come from.  0 = *gp, written by k_setup (packed batches); 1 = this block sizes the grid from k_bounds'
 // partial boxes; 2 = from all the atoms, read by this block itself (inputs of a few thousand atoms: a handful of blocks, each a few trips
 // over arrays that sit in the L2 -- two launches less on a call that is a chain of launches and little else).  Block 0 publishes.
-constexpr uint32_t kCidAllAtoms = 12288;  // BOX = 2 up to here (launch_grid)
+constexpr uint32_t kCidAllAtoms = 12288;  // BOX = 2 up to here (launch_grid).  Measured against 2048 and "never" (tests/microbench/ab_r4cid.sh): per call
+                                          // 44 / 44 / 50 us at 700 atoms, 48 / 52 / 53 at 4000, 53 / 55 / 55 at 8000, 56 / 57 / 57 at 12 000; a 1024-thread
+                                          // block for the pass over all the atoms (three trips instead of twelve) loses more to its barriers than it gains
 template <int BOX>
 __global__ __launch_bounds__(kCidThreads, 4) void k_cellid(DevAtoms in, GridParams *gp, DevParams *prm, const double *partials, uint32_t n_partials, double cutoff,
                                                         uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr, uint32_t *cell_of_atom,

@@ -478,6 +478,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
     const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar, dprm->s_cov_max};
     const double r2m = gp->r2m;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // DIRECT: wave-task = the wave's index in the launch (one each: the launcher sends as many waves as there are wave-tasks), so the home
+    // records can be asked for right here, with the tables -- one round trip less in a call that is a short chain of them.  (Slots past the
+    // last heavy atom read whatever the workspace holds there: allocated, and masked by `have` below.)
+    float4 home_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    Fat fat_pre{};
+    if (DIRECT) {
+        const uint32_t a0 = ((blockIdx.x * (uint32_t)WAVES + wave) / (uint32_t)SPLIT) * 64u + lane;
+        home_pre = so.rec[a0]; fat_pre = so.fat[a0];
+    }
     load_tables_e(tb, dprm);
     if (threadIdx.x == 0) {
         bl.alloc_state = kAllocEmpty | kChunkE;  // "exhausted": the first allocation fetches a chunk
@@ -485,7 +495,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
         bl.chunk_shift = chunk_shift_of(kChunkE);
     }
     __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t probe_bits = in.n_res != 0u ? (1u << 29) : 0u;  // residue tables present: CYS SG pairs in the covalent band get their dihedral probe
     // chunks that lie wholly inside the caller's buffer: a batch placed in one of them needs no further capacity test (exact_finish_e's fast tail)
     // (and inside its first 2^32 bytes: the fast path addresses with a 32-bit byte offset; what lies beyond takes the general path)
@@ -499,9 +508,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     uint32_t *ctr = task_ctr + (kEmit * 8 + group) * kTaskCtrStride;
     const uint32_t queue_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)w.queue);
     const uint32_t group_waves = ((gridDim.x - group + n_groups - 1u) / n_groups) * WAVES;
-    uint32_t t = g_lo + (blockIdx.x / n_groups) * WAVES + wave;
+    uint32_t t = DIRECT ? blockIdx.x * (uint32_t)WAVES + wave : g_lo + (blockIdx.x / n_groups) * WAVES + wave;
+    const uint32_t t_end = DIRECT ? n_tasks : g_hi;
 #pragma unroll 1
-    while (t < g_hi) {
+    while (t < t_end) {
         constexpr uint32_t kSubs = SPLIT == 8 ? 2u : 1u;  // SPLIT == 8: two waves per kind set, on alternate 32-test runs
         const uint32_t slot0 = (t / (uint32_t)SPLIT) * 64u, part = (t % (uint32_t)SPLIT) / kSubs, sub = (t % (uint32_t)SPLIT) % kSubs;
         const int k_lo = SPLIT == 1 ? 0 : (part == 0u ? 0 : (int)part + 1), k_hi = SPLIT == 1 ? 5 : (int)part + 2;  // window kinds of this wave-task
@@ -514,8 +524,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
             u32x4 hxy = {0u, 0u, 0u, 0u}, hzp = {0u, 0u, 0u, 0u};
             unsigned long long hkey = 0ull;
             if (have) {
-                home = so.rec[a];
-                const Fat &f = fat_at<false>(so.fat, a);
+                home = DIRECT ? home_pre : so.rec[a];
+                const Fat &f = *(DIRECT ? &fat_pre : &fat_at<false>(so.fat, a));
                 const double fx = f.x, fy = f.y, fz = f.z;
                 hxy = u32x4{(uint32_t)__double2loint(fx), (uint32_t)__double2hiint(fx), (uint32_t)__double2loint(fy), (uint32_t)__double2hiint(fy)};
                 hzp = u32x4{(uint32_t)__double2loint(fz), (uint32_t)__double2hiint(fz), f.pw, f.orig};
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
             const ExactRegs g = exact_issue_e<false>(w, so, 0u, left, lane);
             exact_finish_e<false, ONLY, kChunkE>(g, K, tb, w, bl, left, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg, in, so, pe);
         }
-        if (g_lo + group_waves >= g_hi) break;  // every task of the group was some wave's static first one (small inputs): no round trip to the counter for nothing
+        if (DIRECT || g_lo + group_waves >= g_hi) break;  // every task was some wave's static first one (small inputs): no round trip to the counter for nothing
         uint32_t nxt_task = 0;
         if (lane == 0) nxt_task = atomicAdd(ctr, 1u);  // (drawn only now: a wave that reserved its next task early would hold it hostage at the end of the launch)
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);

@@ -20,6 +20,7 @@ find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -12
 timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tests/batch_timing.py 2048 trace > $OUT/trace.log 2>&1
 python3 $GRAFT_REPO_ROOT/tests/trace_overlap.py $OUT/trace > $OUT/batch_overlap.txt 2>&1; cat $OUT/batch_overlap.txt
 rm -rf $OUT/trace/*/*kernel_trace.csv $OUT/trace/*/*memory_copy_trace.csv 2>/dev/null
+cd $GRAFT_REPO_ROOT
 for mode in deterministic contacts-only; do
   timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --$mode > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err; python3 tests/show_bench.py $OUT/bench_$mode.json | head -2
 done
