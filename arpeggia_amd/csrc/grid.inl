@@ -283,8 +283,11 @@ constexpr uint32_t kCidThreads = 256, kCidPer = 4, kCidTable = 2048;
 constexpr uint32_t kCidAllAtoms = 12288;  // BOX = 2 up to here (launch_grid).  Measured against 2048 and "never" (tests/microbench/ab_r4cid.sh): per call
                                           // 44 / 44 / 50 us at 700 atoms, 48 / 52 / 53 at 4000, 53 / 55 / 55 at 8000, 56 / 57 / 57 at 12 000; a 1024-thread
                                           // block for the pass over all the atoms (three trips instead of twelve) loses more to its barriers than it gains
+// (BOX != 0 holds the grid sizing's registers: 4 waves per SIMD = 1024 blocks resident, which is why the launcher folds only up to kCidFoldAtoms;
+// a pack of 6 x 10^6 atoms ran its 6100 blocks 35 % slower at that occupancy)
+constexpr uint32_t kCidFoldAtoms = 1024u * 1024u;
 template <int BOX>
-__global__ __launch_bounds__(kCidThreads, 4) void k_cellid(DevAtoms in, GridParams *gp, DevParams *prm, const double *partials, uint32_t n_partials, double cutoff,
+__global__ __launch_bounds__(kCidThreads, BOX == 0 ? 8 : 4) void k_cellid(DevAtoms in, GridParams *gp, DevParams *prm, const double *partials, uint32_t n_partials, double cutoff,
                                                         uint32_t ncells_cap, unsigned long long *result, uint32_t *task_ctr, uint32_t *cell_of_atom,
                                                         uint32_t *rank_of_atom, uint32_t *cell_count) {
     __shared__ uint32_t t_key[kCidTable], t_cnt[kCidTable];

@@ -658,8 +658,9 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
     auto P1 = [&]() { if (prof) prof->end(st); };
     if (prof) prof->n = 0;
     // One structure: the blocks of k_cellid size the grid themselves (grid.inl setup_block), and below kCidAllAtoms atoms they also find the box.
-    // Packed batches keep the launch of their own (per-model boxes first), and so does the empty input (no k_cellid to fold into).
-    const bool fold = n != 0u && !in.per_model, all_atoms = fold && n <= kCidAllAtoms;
+    // Packed batches keep the launch of their own (per-model boxes first), and so do the empty input (no k_cellid to fold into) and inputs
+    // whose k_cellid blocks no longer fit the chip at once at the folded kernel's occupancy (the launch is noise there).
+    const bool fold = n != 0u && !in.per_model && n <= kCidFoldAtoms, all_atoms = fold && n <= kCidAllAtoms;
     P0("grid_bounds");
     const uint32_t nbb = (n + kBoundsThreads - 1u) / kBoundsThreads, bb = nbb < 1 ? 1 : (nbb < kBoundsBlocks ? nbb : kBoundsBlocks);
     if (!all_atoms) hipLaunchKernelGGL(k_bounds, dim3(bb), dim3(kBoundsThreads), 0, st, in, ws.partials);
