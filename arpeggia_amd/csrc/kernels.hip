@@ -1,8 +1,9 @@
 // HIP kernels of the contact engine, written for gfx950 (MI355X, wave64) only.
 //
 // Pipeline (all on one stream, no host round trip):
-//   k_bounds (+ grid setup) -> k_cellid -> scan(cell_count) -> k_place | k_scatter + k_gather          (grid.inl)
-//   -> k_emit -> k_pairs_deferred -> k_fixup   |   k_pairs<count> -> scan -> k_pairs<fill>    (pairs_emit.inl, pairs.inl)
+//   k_bounds -> k_cellid (sizes the grid first) -> scan(cell_count) -> k_place | k_scatter + k_gather  (grid.inl)
+//   -> k_emit -> probe pass -> k_fixup   |   k_pairs<count> -> scan -> k_pairs<fill>           (pairs_emit.inl, pairs.inl)
+//   below 20 480 atoms: k_cellid (finds the box as well) -> k_scan_one -> k_place -> k_emit (hole-free list, probes inline)
 // It replaces the reference's R*-tree build + serial neighbour walk + rayon classification
 // (src/contacts/complex.rs:189-299) with a uniform-grid cell list and a count/scan/fill pair emitter whose
 // output order is deterministic.  Decisions are made in f64 with the reference's operation order and no FMA

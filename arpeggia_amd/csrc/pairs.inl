@@ -18,7 +18,7 @@
 //   kFillOrdered  writes task t's pairs at the scanned offset of task t: output order is a function of the input only
 //   kEmit         single pass: classified records are compacted per wave and flushed as 64-record units (1 KiB
 //                 coalesced stores) into chunks that a block-level LDS bump allocator carves out of ONE global
-//                 counter (one device atomic per 2048 records).  The few unused chunk tails ("holes", one per
+//                 counter (one device atomic per 4096 records).  The few unused chunk tails ("holes", one per
 //                 block) are closed afterwards by k_fixup, which moves the tail of the array into them.
 enum PairMode { kCountTasks = 0, kFillOrdered = 1, kEmit = 2, kCountContacts = 3 };
 //   kCountContacts  kCountTasks for ARP_FLAG_CONTACTS_ONLY: classifies, counts only the pairs with an interaction
@@ -36,7 +36,7 @@ constexpr uint32_t kESlotBits = 24;        // k_emit (pairs_emit.inl): neighbour
 // records per global allocation (one device atomic each).  The wave whose allocation crosses the end of the block's chunk fetches the
 // next one while the block's other waves sleep: 2048 -> 4096 halves those stalls (emit 221 -> 208 us); 8192 gains 2 us more and costs
 // the fix-up 8 us (holes grow with the chunk).
-constexpr uint32_t kChunkRecords = 4096, kSmallChunkRecords = 2048, kTinyChunkRecords = 256;  // records per allocation chunk (powers of two; the smaller ones: k_emit's 4-wave kernels; the smallest inputs allocate per batch)
+constexpr uint32_t kChunkRecords = 4096, kSmallChunkRecords = 2048;  // records per allocation chunk (powers of two; the smaller one: k_emit's four-way task split; its 4-wave kernels stage and flush instead)
 
 template <int MODE>
 struct WaveLds {                                  // per-wave LDS working set
