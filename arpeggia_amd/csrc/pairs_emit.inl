@@ -455,7 +455,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
 // alternate 32-test runs: a small input has few tasks and each is a long chain of dependent round trips, so more waves on a
 // fraction of the chain each is what shortens the launch
 // DIRECT (with SPLIT 8, the smallest inputs): no allocation chunks -- a batch takes its places from the global record counter, the list has
-// no holes and the launch sequence no fix-up kernel (alloc_direct, direct_finish in pairs.inl)
+// no holes and the launch sequence no fix-up kernel (stage_flush_e above; engine.cpp finish_result)
 struct StageLdsE { uint4 rec[4][kStageRecords]; uint32_t wave_n[4]; unsigned long long base; };
 struct NoStageLdsE { uint4 rec[1][1]; uint32_t wave_n[1]; unsigned long long base; };
 template <int WAVES, int SPLIT, bool ONLY, bool DIRECT = false>

@@ -430,6 +430,21 @@ def test_enqueue_with_resident_buffers_and_capacity_error(ctx):
     c2.enqueue(atoms, prm, out.data_ptr(), len(want)); c2.result()
     prof = c2.profile_read()
     assert "pairs_emit" in prof and all(v >= 0 for v in prof.values())
+    # 6bft runs the hole-free sequence of small inputs; the same two checks on the chunked sequence with its fix-up (30 000 atoms): a buffer of
+    # exactly P records suffices (the holes' overflow lives in the engine's scratch until they are closed), and a short one reports P
+    soa_m = aa.Structure.from_records(synth.gen_s2(30000, seed=3), hierarchy=True).soa("/")
+    want_m = ctx.atomic_contacts(soa_m)
+    dev_m = {k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda() for k, v in soa_m.items()}
+    atoms_m = aa.atoms_from_arrays(dev_m, location=_lib.ARP_MEM_DEVICE, keep=keep)
+    out_m = torch.empty((len(want_m), 4), dtype=torch.int32, device="cuda")
+    c2.enqueue(atoms_m, prm, out_m.data_ptr(), len(want_m))
+    assert c2.result() == len(want_m)
+    assert np.array_equal(canon(out_m.cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1)), canon(want_m))
+    c2.enqueue(atoms_m, prm, small.data_ptr(), 900)
+    with pytest.raises(aa.ArpeggiaError) as e:
+        c2.result()
+    assert e.value.status == _lib.ARP_ERR_CAPACITY and str(len(want_m)) in str(e.value)
+    assert torch.equal(small[900:], guard[900:])
 
 
 def test_batch_of_structures(ctx):
