@@ -485,7 +485,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     float4 home_pre = make_float4(0.f, 0.f, 0.f, 0.f);
     Fat fat_pre{};
     if (DIRECT) {
-        const uint32_t a0 = ((blockIdx.x * (uint32_t)WAVES + wave) / (uint32_t)SPLIT) * 64u + lane;
+        // (clamped to what the workspace allocates behind the last atom, engine.cpp ensure_workspace: n_cap + 64 records; the launch rounds the
+        // wave-tasks up to whole blocks, so the last block's spare waves would otherwise read up to 62 records further)
+        const uint32_t a0 = min(((blockIdx.x * (uint32_t)WAVES + wave) / (uint32_t)SPLIT) * 64u + lane, in.n + 63u);
         home_pre = so.rec[a0]; fat_pre = so.fat[a0];
     }
     load_tables_e(tb, dprm);
