@@ -308,6 +308,12 @@ def test_all_hydrogen_and_coincident_atoms(ctx):
     got, want = run_both(ctx, prod, orc)
     assert_pairs_equal(got, want)
     assert len(got) == 299 * 298 // 2 and (got["kind"] == 1).all()
+    # 560 atoms on one point: 156 k pairs from nine tasks -- more than the context's first guess for a buffer (65 536 records), so the hole-free
+    # sequence of small inputs has to report the size (the host derives the overflow from the record counter) and the call is repeated
+    prod, orc = _both_from(_mini(np.full((560, 3), -3.5)))
+    got, want = run_both(aa.Context(0), prod, orc)
+    assert_pairs_equal(got, want)
+    assert len(got) == 559 * 558 // 2 > 65536
 
 
 def test_sparse_huge_extent_and_large_coordinates(ctx):
