@@ -19,6 +19,8 @@ ARP_NONE = 0xFFFFFFFF
 ARP_FLAG_DETERMINISTIC = 0x1
 ARP_FLAG_CONTACTS_ONLY = 0x2
 ARP_FLAG_NO_SPECULATION = 0x4
+ARP_FLAG_RESIDUE_RUNS = 0x8
+ARP_FLAG_NO_RESIDUE_RUNS = 0x10
 
 ATTR = dict(
     ELEM_MASK=0xF, DONOR=0x10, ACCEPTOR=0x20, WEAK_DONOR=0x40, POS=0x80, NEG=0x100, HYDROPHOBIC=0x200, CYS_SG=0x400,

@@ -48,17 +48,21 @@ def device_count() -> int:
 
 
 def default_params(vdw_comp: float = 0.1, dist_cutoff: float = 6.5, deterministic: bool = False, contacts_only: bool = False,
-                   no_speculation: bool = False) -> _lib.arp_params:
+                   no_speculation: bool = False, residue_runs: bool | None = None) -> _lib.arp_params:
     """deterministic=True selects the two-pass ordered emitter (ARP_FLAG_DETERMINISTIC): identical bytes run to run.
     contacts_only=True drops candidates without any interaction on the device (ARP_FLAG_CONTACTS_ONLY).
     no_speculation=True (ARP_FLAG_NO_SPECULATION): Context.enqueue always launches the probe pass, so that work ordered on the stream behind
-    the enqueue sees final records (include/arpeggia_amd.h)."""
+    the enqueue sees final records (include/arpeggia_amd.h).
+    residue_runs: a hint about the input, never a change of the result -- True asks for the kernels that apply the reference's residue rule
+    (complex.rs:108-113) before the exact phase (ARP_FLAG_RESIDUE_RUNS), False rules them out (ARP_FLAG_NO_RESIDUE_RUNS), None lets the
+    engine choose from a sample of the previous call's atoms."""
     p = _lib.arp_params()
     lib.arp_default_params(C.byref(p))
     p.vdw_comp = vdw_comp
     p.dist_cutoff = dist_cutoff
     p.flags = ((_lib.ARP_FLAG_DETERMINISTIC if deterministic else 0) | (_lib.ARP_FLAG_CONTACTS_ONLY if contacts_only else 0)
-               | (_lib.ARP_FLAG_NO_SPECULATION if no_speculation else 0))
+               | (_lib.ARP_FLAG_NO_SPECULATION if no_speculation else 0)
+               | (0 if residue_runs is None else (_lib.ARP_FLAG_RESIDUE_RUNS if residue_runs else _lib.ARP_FLAG_NO_RESIDUE_RUNS)))
     return p
 
 

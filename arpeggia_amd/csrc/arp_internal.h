@@ -48,6 +48,9 @@ struct GridParams {
     double r2m;           // prefilter threshold on d^2 in f64: r2 + storage margin + dot-form margin
     const double *model_org;  // packed batches: per model {origin xyz, midpoint xyz} -- every member sits in a grid slab of its own
                               // position, however far apart the members are in space; nullptr = one origin for all models
+    uint32_t rk_bad;      // k_place met a residue ordinal or chain rank that does not fit the 32-bit residue word (Sorted::rkey): the residue-rule
+                          // kernels (k_emit<.., RES>) then reject nothing early -- the exact phase decides on the real keys, as always
+    uint32_t pad_;
 };
 
 // Device view of the caller's SoA (all device pointers).
@@ -80,7 +83,13 @@ constexpr uint32_t kPwLigand = 1u << 24, kPwReceptor = 1u << 25, kPwResHasH = 1u
 struct Sorted {
     float4 *rec;          // {x-mx, y-my, z-mz as f32, |.|^2 of those three}  -- prefilter operand, 16 B
     Fat *fat;
+    uint32_t *rkey;       // residue word chain rank << 20 | residue ordinal (kRkOrdBits): two atoms whose words differ by at most 1 are of one residue
+                          // or of sequence neighbours in one chain and never pair (complex.rs:108-113) -- k_emit<.., RES> drops such prefilter
+                          // survivors before the gathers.  Written by k_place<true> only, valid while GridParams::rk_bad == 0
 };
+// the residue word: 20 bits of residue ordinal (at most 2^20 - 3, so that the words of two chains are at least 3 apart) + 11 bits of chain rank
+// (bit 31 stays clear: the home side disables the rule with a word no neighbour word comes within 2^30 of)
+constexpr uint32_t kRkOrdBits = 20, kRkOrdMax = (1u << kRkOrdBits) - 3u, kRkChainMax = (1u << 11) - 1u, kRkOff = 0xC0000000u;
 
 // Same-address (and same-line) device atomics serialise in one L2 channel at ~90 ns each: the task counters of the eight XCD
 // groups sit in separate 128-byte lines (measured: sharing one line cost the emit kernel 155 us of hand-out time).
@@ -103,7 +112,8 @@ struct Workspace {
     unsigned long long *task_base;  // n/64 + 2
     uint32_t *scan_tmp;       // block sums (1024 + 1)
     unsigned long long *scan_tmp64;
-    unsigned long long *result;  // [0] = total pairs, [1] = flags, [2] = emit allocator head (64-record units), [3] = deferred candidates
+    unsigned long long *result;  // [0] = total pairs, [1] = flags, [2] = emit allocator head (64-record units), [3] = deferred candidates,
+                                 // [4] = how many of the first 255 atoms carry their predecessor's residue word (k_place: the launcher's hint for the next call)
     ulonglong2 *hole_list;    // emit mode: one (start, length) per block
     arp_pair *scratch;        // emit mode: home of positions >= the caller's capacity until k_fixup has closed the holes
     unsigned long long scratch_cap;
@@ -142,12 +152,13 @@ struct Profiler {
 };
 
 // Launch wrappers (kernels.hip / pairs.inl).  All asynchronous on `st`.
-void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered);
+void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered, bool want_rkey = false);
 void launch_count(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, unsigned long long capacity, bool have_out, bool contacts_only);
 void launch_fill_ordered(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof,
                          bool contacts_only);
 bool launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
-                 bool skip_deferred);  // true: the hole-free sequence of small inputs ran (the host derives result[0] and the flags: engine.cpp finish_result)
+                 bool skip_deferred, bool res_filter = false);  // true: the hole-free sequence of small inputs ran (the host derives result[0] and the flags: engine.cpp finish_result)
+bool emit_takes_res_filter(const DevAtoms &in);  // the single-pass emitter has residue-rule kernels for an input of this size (the grid build then writes Sorted::rkey)
 unsigned long long emit_scratch_records();
 void launch_neighbor_sum(const DevAtoms &in, const Workspace &ws, double radius, double r2, const float *weight, float *out, hipStream_t st, Profiler *prof);
 void launch_pack_fix(const PackArrays &pa, hipStream_t st);

@@ -121,7 +121,12 @@ struct arp_context {
     unsigned long long *h_offsets = nullptr;  // pinned: per-member offsets into the grouped list (+ the pack status word)
     uint64_t h_offsets_cap = 0;
     DevParams *h_params = nullptr;         // pinned
-    unsigned long long *h_result = nullptr;  // pinned [4]: pairs, status flags, emit allocator head, deferred-list chunks
+    unsigned long long *h_result = nullptr;  // pinned [kResultWords]: pairs, status flags, emit allocator head, deferred-list chunks, residue-run sample
+    // Residue-rule memo: the last input's residues were runs of atoms (k_place's sample, result[4]) -- the next call's launcher then picks the
+    // kernels that apply the reference's residue rule before the gathers (k_emit<.., RES>).  Same result either way; ARP_FLAG_RESIDUE_RUNS /
+    // ARP_FLAG_NO_RESIDUE_RUNS overrule the memo.
+    bool res_hint = false;
+    bool rkey_valid = false;               // the workspace's residue words (Sorted::rkey) belong to the cell list that was built last
     // Deferred-pass memo: the arrays (address + length) of the last single-pass call that deferred NOTHING to the probe pass (no hydrogens,
     // no CYS SG pair in the covalent band -- every X-ray structure without hydrogens).  The next call on the same arrays does not launch
     // k_pairs_deferred; should it defer after all (the caller rewrote the arrays), k_fixup raises status bit 128 and the call is repeated
@@ -144,6 +149,18 @@ struct arp_context {
     arp_pair *last_out = nullptr;
     Profiler prof;
 };
+
+constexpr size_t kResultWords = 5;
+constexpr unsigned long long kResRunsMin = 64;  // of the 255 atoms k_place samples
+
+// Builds the cell list of a call.  Decides whether the pair pass will run the residue-rule kernels (then k_place also writes the residue words).
+static void grid_for_call(arp_context *ctx, const DevAtoms &d, const arp_params *params, Profiler *prof, bool ordered) {
+    bool res = !ordered && emit_takes_res_filter(d);
+    if (res) res = (params->flags & ARP_FLAG_RESIDUE_RUNS) ? true : ((params->flags & ARP_FLAG_NO_RESIDUE_RUNS) ? false : ctx->res_hint);
+    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered, res);
+    ctx->rkey_valid = res;
+}
+static void note_residue_runs(arp_context *ctx) { ctx->res_hint = ctx->h_result[4] >= kResRunsMin; }
 
 static arp_status check_device(arp_context *ctx) {
     if (!ctx) { set_error("null context"); return ARP_ERR_BAD_INPUT; }
@@ -180,7 +197,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.partials, 1024 * 8); A(w.tickets, 4); A(w.grid, 1); A(w.params, 1);
     A(w.cell_of_atom, cap); A(w.rank_of_atom, cap); A(w.cell_count, ccap + 1); A(w.cell_start, ccap + 1);
     A(w.perm, cap); A(w.slot_cell, cap);
-    A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64);
+    A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.rkey, cap + 64);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
     A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 32);  // scan_tmp*: >= kScanBlocks + 1
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
@@ -198,7 +215,7 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
         // (nil)": an intermediate build launched k_bounds with the then-new `partials` member not yet allocated here.  A member
         // added to Workspace without its allocation now fails this check on the host instead of faulting on the device.)
         const void *members[] = {w.partials, w.tickets, w.grid, w.params, w.cell_of_atom, w.rank_of_atom, w.cell_count, w.cell_start, w.perm, w.slot_cell,
-                                 w.sorted.rec, w.sorted.fat, w.task_count, w.task_base, w.scan_tmp, w.scan_tmp64, w.result, w.hole_list, w.scratch,
+                                 w.sorted.rec, w.sorted.fat, w.sorted.rkey, w.task_count, w.task_base, w.scan_tmp, w.scan_tmp64, w.result, w.hole_list, w.scratch,
                                  w.task_ctr, w.defer_list, w.model_box, w.model_org};
         for (const void *m : members)
             if (!m) { free_workspace(ctx); set_error("internal error: a workspace member was not allocated"); return ARP_ERR_HIP; }
@@ -220,7 +237,7 @@ extern "C" arp_status arp_context_create(int32_t device, arp_context **out) try 
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_params, sizeof(DevParams), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 4 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) {
         set_error("HIP error %d (%s) creating the context", (int)e, hipGetErrorString(e));
         arp_context_destroy(ctx);
@@ -473,7 +490,7 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
     Profiler *prof = ctx->prof.enabled ? &ctx->prof : nullptr;
     const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
-    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
+    grid_for_call(ctx, d, params, prof, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
     bool direct = false;
     if (!out || capacity == 0) {
         launch_count(d, ctx->ws, ctx->stream, prof, 0, true, only);  // size query: reports ARP_ERR_CAPACITY + the count
@@ -482,11 +499,11 @@ extern "C" arp_status arp_contacts_atomic_enqueue(arp_context *ctx, const arp_at
         launch_fill_ordered(d, ctx->ws, out, capacity, ctx->stream, prof, only);
     } else {
         ctx->last_skip = !(params->flags & ARP_FLAG_NO_SPECULATION) && skip_deferred_pass(ctx, d);
-        direct = launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only, ctx->last_skip);
+        direct = launch_emit(d, ctx->ws, out, capacity, ctx->stream, prof, only, ctx->last_skip, ctx->rkey_valid);
     }
     ctx->last_direct = direct;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, kResultWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     ctx->last_capacity = capacity;
     ctx->last_atoms = *atoms; ctx->last_out = out;  // (device pointers: the caller keeps them alive until arp_contacts_atomic_result)
     ctx->pending = true;
@@ -501,6 +518,7 @@ extern "C" arp_status arp_contacts_atomic_result(arp_context *ctx, uint64_t *n_p
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->pending = false;
         finish_result(ctx, ctx->last_direct, ctx->last_skip, ctx->last_capacity);
+        note_residue_runs(ctx);
         if (n_pairs) *n_pairs = ctx->h_result[0];
         const arp_atoms again = ctx->last_atoms;
         const arp_params prm = ctx->last_params;
@@ -539,13 +557,14 @@ static arp_status single_pass_into_context_buffer(arp_context *ctx, uint64_t n_a
             HIP_TRY(hipMalloc((void **)&ctx->out_buf, want * sizeof(arp_pair)));
             ctx->out_cap = want;
         }
-        launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, false); ctx->grid_x = d.x; ctx->grid_n = d.n;
+        grid_for_call(ctx, d, params, prof, false); ctx->grid_x = d.x; ctx->grid_n = d.n;
         const bool skip = skip_deferred_pass(ctx, d);
-        const bool direct = launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0, skip);
+        const bool direct = launch_emit(d, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0, skip, ctx->rkey_valid);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, kResultWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         finish_result(ctx, direct, skip, ctx->out_cap);
+        note_residue_runs(ctx);
         note_deferred(ctx, d, skip);
         if ((s = flags_to_status(ctx->h_result[1])) == kRetryDeferPass) { attempt--; continue; }  // the memo was stale: once more, with the probe pass
         if (s != ARP_OK) return s;
@@ -616,10 +635,10 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     // count pass -> output size -> ordered fill or single-pass emit.  With ARP_FLAG_CONTACTS_ONLY the single-pass emitter
     // sizes the device buffer by the (cheap) candidate count, an upper bound; the ordered one needs the exact filtered counts.
     const bool ordered = (params->flags & ARP_FLAG_DETERMINISTIC) != 0, only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
-    launch_grid(d, ctx->ws, ctx->stream, prof, params->dist_cutoff, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
+    grid_for_call(ctx, d, params, prof, ordered); ctx->grid_x = d.x; ctx->grid_n = d.n;
     launch_count(d, ctx->ws, ctx->stream, prof, 0, false, only && ordered);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, kResultWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) return s;
     unsigned long long total = ctx->h_result[0];
@@ -628,11 +647,11 @@ static arp_status contacts_atomic_once(arp_context *ctx, const arp_atoms *atoms,
     HIP_TRY(hipMalloc((void **)&dev, total * sizeof(arp_pair)));
     bool direct = false;
     if (params->flags & ARP_FLAG_DETERMINISTIC) launch_fill_ordered(d, ctx->ws, dev, total, ctx->stream, prof, only);
-    else direct = launch_emit(d, ctx->ws, dev, total, ctx->stream, prof, only, false);
+    else direct = launch_emit(d, ctx->ws, dev, total, ctx->stream, prof, only, false, ctx->rkey_valid);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_result, ctx->ws.result, kResultWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) finish_result(ctx, direct, false, total);
+    if (e == hipSuccess) { finish_result(ctx, direct, false, total); note_residue_runs(ctx); }
     if (e != hipSuccess) { (void)hipFree(dev); set_error("HIP error %d (%s) in the fill pass", (int)e, hipGetErrorString(e)); return ARP_ERR_HIP; }
     if ((s = flags_to_status(ctx->h_result[1])) != ARP_OK) { (void)hipFree(dev); return s; }
     total = std::min<unsigned long long>(total, ctx->h_result[0]);  // fewer than the candidates with ARP_FLAG_CONTACTS_ONLY
@@ -844,16 +863,16 @@ arp_status enqueue_pack_kernels(BatchSlot &sl, const arp_params *params) {
     arp_context *ctx = sl.ctx;
     const bool only = (params->flags & ARP_FLAG_CONTACTS_ONLY) != 0;
     Profiler *prof = nullptr;
-    launch_grid(sl.dev, ctx->ws, ctx->stream, prof, params->dist_cutoff, sl.ordered); ctx->grid_x = nullptr; ctx->grid_n = 0;  // (a pack's grid: per-model origins)
+    grid_for_call(ctx, sl.dev, params, prof, sl.ordered); ctx->grid_x = nullptr; ctx->grid_n = 0;  // (a pack's grid: per-model origins)
     if (sl.ordered) {
         launch_count(sl.dev, ctx->ws, ctx->stream, prof, ctx->out_cap, true, only);
         launch_fill_ordered(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only);
     } else {
-        launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only, false);
+        launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only, false, ctx->rkey_valid);
     }
     launch_pack_split(sl.pa, ctx->ws.result, ctx->out_buf, ctx->grp_buf, sl.ordered, ctx->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, kResultWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_offsets, sl.pa.offset, (sl.pa.K + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_offsets + sl.pa.K + 1, sl.pa.status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     return ARP_OK;
@@ -943,6 +962,7 @@ arp_status finalize_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         lap("finalize: wait for kernels");
         const uint32_t pack_status = *reinterpret_cast<const uint32_t *>(ctx->h_offsets + K + 1);
+        note_residue_runs(ctx);
         s = flags_to_status(ctx->h_result[1]);
         if (s == kRetryDefer && attempt < 4) {  // deferred-probe list too small: grow it, run the pack's kernels again
             if ((s = grow_defer_list(ctx, pk.n)) != ARP_OK) return s;
@@ -1143,7 +1163,7 @@ extern "C" arp_status arp_sap_neighbor_sum(arp_context *ctx, uint64_t n, const d
     HIP_TRY(hipGetLastError());
     float *h_out = (float *)(pin + ((n * 4 + 255u) & ~255ull));
     HIP_TRY(hipMemcpyAsync(h_out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, kResultWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->ws.grid) {  // non-finite coordinates are reported by the grid build through the fix-up kernel only; check here
         for (uint64_t i = 0; i < n; i++)

@@ -54,6 +54,7 @@ DEVFN float grid_setup(const double lo_in[3], const double hi_in[3], bool empty,
     g->ncells = g->nx * g->ny * g->nzt;
     g->n_heavy = 0; g->n_tasks = 0;
     g->bad = bad;
+    g->rk_bad = 0u; g->pad_ = 0u;
     // f32 prefilter: relative coordinates carry <= 2^-24 * extent of rounding each; a 10x-safe bound on the
     // induced error of dx^2+dy^2+dz^2 near the cutoff (derivation in DESIGN.md "Prefilter margin")
     const double M = fmax(ext[0], fmax(ext[1], ext[2])) + edge;
@@ -529,12 +530,29 @@ DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so
 // counters say the kernel waits on vector-memory ISSUE, i.e. on the scattered 64-byte writes, not on load latency; one atom per thread stays,
 // which also keeps four times as many blocks for inputs that do not fill the chip.)
 constexpr uint32_t kPlacePer = 1;
+// The residue word of an atom (arp_internal.h Sorted::rkey); `bad`: the atom's ordinal or chain rank does not fit it.
+DEVFN uint32_t residue_word(uint32_t res_ord, uint32_t chain_rank, bool *bad) {
+    *bad = (res_ord > kRkOrdMax) | (chain_rank > kRkChainMax);
+    return ((chain_rank & kRkChainMax) << kRkOrdBits) + (res_ord & ((1u << kRkOrdBits) - 1u));
+}
+// RKEY: also write the residue words of the slots (the launcher is about to run the residue-rule kernels, k_emit<.., RES>).
+// Block 0 always leaves result[4] = how many of atoms 1..255 carry their predecessor's residue word: inputs whose residues are runs of atoms
+// (every protein; not a cloud of one-atom residues) are the ones the residue-rule kernels pay for, and the engine picks the kernels of the
+// NEXT call by it (engine.cpp res_filter_for) -- a choice between two kernels with identical results, never a correctness assumption.
+template <bool RKEY>
 __global__ __launch_bounds__(256) void k_place(DevAtoms in, GridParams *gp, const uint32_t *cell_start, const uint32_t *cell_of_atom,
-                                               const uint32_t *rank_of_atom, Sorted so) {
+                                               const uint32_t *rank_of_atom, Sorted so, unsigned long long *result) {
     const uint32_t i0 = blockIdx.x * (256u * kPlacePer) + threadIdx.x;
     if (i0 == 0) { const uint32_t n_heavy = cell_start[gp->ncells]; gp->n_heavy = n_heavy; gp->n_tasks = (n_heavy + 63u) / 64u; }
     if (in.n == 0u) return;
     const uint32_t last = in.n - 1u;
+    if (blockIdx.x == 0u) {  // (block-uniform)
+        bool b0, b1;
+        const uint32_t ip = threadIdx.x ? threadIdx.x - 1u : 0u, iq = min(threadIdx.x, last);
+        const uint32_t wp = residue_word(in.res_ord[min(ip, last)], in.chain_rank[min(ip, last)], &b0), wq = residue_word(in.res_ord[iq], in.chain_rank[iq], &b1);
+        const int runs = __syncthreads_count(threadIdx.x != 0u && threadIdx.x <= last && wp == wq && !b0 && !b1);
+        if (threadIdx.x == 0u) result[4] = (unsigned long long)runs;
+    }
     const bool any_h = in.n_res != 0u && in.res_h_ptr[in.n_res] != 0u;  // (wave-uniform)
     const double *morg = gp->model_org;
     const double gmx = gp->mx, gmy = gp->my, gmz = gp->mz;
@@ -576,6 +594,12 @@ __global__ __launch_bounds__(256) void k_place(DevAtoms in, GridParams *gp, cons
         f.crm = cr[u]; f.orig = i; f.cell = c[u];
         f.attr = attr | (has_h ? kAttrResHasH : 0u);
         so.fat[slot] = f;
+        if (RKEY) {
+            bool bad;
+            so.rkey[slot] = residue_word(ro[u], cr[u], &bad);
+            // (an input of 70 000 chains would otherwise queue 70 000 atomics on one word: the flag is read first, so only the first few set it)
+            if (bad && __hip_atomic_load(&gp->rk_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&gp->rk_bad, 1u);
+        }
     }
 }
 

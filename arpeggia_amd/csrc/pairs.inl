@@ -651,7 +651,7 @@ static uint32_t blocks_for(uint32_t n, uint32_t cap) {
 
 unsigned long long emit_scratch_records() { return (unsigned long long)kMaxHoles * kChunkRecords; }
 
-void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered) {
+void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profiler *prof, double cutoff, bool ordered, bool want_rkey) {
     const uint32_t n = in.n;
     const uint32_t nb = (n + 255) / 256;
     auto P0 = [&](const char *nm) { if (prof) prof->begin(nm, st); };
@@ -691,8 +691,9 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
         hipLaunchKernelGGL(k_gather, dim3(nb ? nb : 1), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.perm,
                            (const uint32_t *)ws.slot_cell, ws.sorted);
     } else {
-        hipLaunchKernelGGL(k_place, dim3((n + 256u * kPlacePer - 1u) / (256u * kPlacePer) + (n ? 0u : 1u)), dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.cell_of_atom,
-                           (const uint32_t *)ws.rank_of_atom, ws.sorted);
+        const dim3 pb((n + 256u * kPlacePer - 1u) / (256u * kPlacePer) + (n ? 0u : 1u));
+        if (want_rkey) hipLaunchKernelGGL(k_place<true>, pb, dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.rank_of_atom, ws.sorted, ws.result);
+        else hipLaunchKernelGGL(k_place<false>, pb, dim3(256), 0, st, in, ws.grid, (const uint32_t *)ws.cell_start, (const uint32_t *)ws.cell_of_atom, (const uint32_t *)ws.rank_of_atom, ws.sorted, ws.result);
     }
     P1();
 }
@@ -756,12 +757,17 @@ static void launch_emit_tail(const DevAtoms &in, const Workspace &ws, const Emit
     if (prof) prof->end(st);
 }
 bool launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
-                   bool skip_deferred);
+                   bool skip_deferred, bool res_filter);
+// the residue-rule kernels exist for the inputs launch_emit_e gives a 12-wave kernel: whoever builds the grid asks this before k_place runs
+bool emit_takes_res_filter(const DevAtoms &in) {
+    const uint32_t tasks = (in.n + 63u) / 64u;
+    return in.n < (1u << kESlotBits) - 64u && !(tasks < 320u && !in.per_model);
+}
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 // Returns true when the hole-free sequence of small inputs ran: result[0] and the flags k_fixup sets are then the host's to derive from
 // result[2] (the records) and result[3] (the deferred list's chunks) -- engine.cpp finish_result.
 bool launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
-                 bool skip_deferred) {
+                 bool skip_deferred, bool res_filter) {
     if (in.n >= kBigSlots) {  // beyond the 32-bit record offsets of the single-pass kernels: count + ordered fill with inline probes
         launch_count(in, ws, st, prof, capacity, true, contacts_only);
         launch_fill_ordered(in, ws, out, capacity, st, prof, contacts_only);
@@ -770,7 +776,7 @@ bool launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
     // The default is k_emit (pairs_emit.inl).  This file's k_pairs<kEmit> -- both exact operands gathered, 8-byte queue entries -- is the
     // one alternative kept: it takes the inputs beyond k_emit's 2^24 slots, and ARP_EMIT_KERNEL=gather selects it for the parity suite.
     static const bool gather = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'g'; }();
-    if (!gather && in.n < (1u << kESlotBits) - 64u) return launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred);
+    if (!gather && in.n < (1u << kESlotBits) - 64u) return launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred, res_filter && emit_takes_res_filter(in));
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t nb = blocks_for(in.n, kEmitBlocks);
     if (prof) prof->begin("pairs_emit", st);

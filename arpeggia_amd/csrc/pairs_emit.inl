@@ -44,9 +44,14 @@ struct WaveLdsE {
     unsigned long long hkey[64];              // ... and the chain key crm << 32 | res_ord
     uint32_t queue[kEQueue];                  // phase-1 survivors: home lane << 26 | neighbour slot
 };
-struct alignas(16) TablesE {                  // block-shared decision tables (14.3 KB)
-    double s_clash[256], s_cov[256], s_vdw[256];   // bounds of the element pair (vdw.rs:32-43), index = class a << 4 | class b
+struct WaveLdsR { WaveLdsE e; uint32_t nkey[kEChunk + kEGroup]; };  // RES: + the residue words of the staged chunk (Sorted::rkey)
+struct WaveLdsN { WaveLdsE e; };
+struct alignas(16) TablesE {                  // block-shared decision tables (10 KB)
+    double s_vdw[256];                        // van-der-Waals bound of the element pair (vdw.rs:41), index = class a << 4 | class b
     uint32_t lut[2048];                       // rows of a pair: index = W | Lg << 7 | Le << 9 (pair_lut2_entry)
+    // (round 5: the clash and covalent bounds of the element pair, vdw.rs:33-34, are read from the parameter block in global memory: they are
+    // only looked at behind m_close -- a candidate below the largest covalent bound of any element pair present -- and their 4 KB of LDS per
+    // block are what the residue words of the RES kernels' staged chunks live in)
 };
 
 // Table entry for the seven pair predicates W (Fat::pw, classify_fast), the level Lg against the fixed bounds {4.5, 4.0, 3.5} and the
@@ -71,9 +76,9 @@ constexpr Lut2 make_lut2() {
 }
 __device__ const Lut2 kLut2 = make_lut2();
 DEVFN void load_tables_e(TablesE &tb, const DevParams *dprm) {
-    const double *src = dprm->s_clash;
-    double *dst = tb.s_clash;
-    for (uint32_t k = threadIdx.x; k < 3u * 256u; k += blockDim.x) dst[k] = src[k];
+    const double *src = dprm->s_vdw;
+    double *dst = tb.s_vdw;
+    for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) dst[k] = src[k];
     const uint4 *lsrc = reinterpret_cast<const uint4 *>(kLut2.v);
     uint4 *ldst = reinterpret_cast<uint4 *>(tb.lut);
     for (uint32_t k = threadIdx.x; k < 512u; k += blockDim.x) ldst[k] = lsrc[k];
@@ -112,6 +117,57 @@ DEVFN void compact_rounds_e(uint32_t &mask, uint32_t tag, uint32_t &qbyte, uint3
         "s_mov_b64 exec, %[save]"
         : [mask] "+v"(mask), [qb] "+s"(qbyte), [t] "=&v"(t), [lz] "=&v"(lz), [ent] "=&v"(ent), [bm] "=&v"(bm), [c] "=&s"(c), [save] "=&s"(save)
         : [tag] "v"(tag), [top] "s"(0x80000000u), [qf] "s"(qfull)
+        : "vcc", "scc", "memory");
+}
+
+// The same rounds with the reference's residue rule applied to every survivor BEFORE it is appended (k_emit<.., RES>): two atoms of one residue,
+// or of sequence neighbours in one chain, never pair (complex.rs:108-113), and in an input whose residues are runs of atoms (every protein)
+// a third of an atom's geometric neighbours are such atoms -- which otherwise ride through the gathers and the exact phase only to be dropped
+// there (profiles/r04_emit_experiments.txt, section 11).  The staged chunk carries the residue word of every record (Sorted::rkey -> WaveLdsR::nkey);
+// kbase = LDS byte address of the word of the run's test 0 for this lane, kh1 = the home atom's word - 1: the survivor is dropped when
+// (its word - kh1) is 0, 1 or 2, i.e. when the words differ by at most 1 -- which, by the word's construction, happens only for atoms the
+// reference's rule drops (a chain's ordinals stop 3 short of the next chain's; kh1 = kRkOff switches the rule off).  The exact phase still
+// applies the rule itself on the real keys: this is an early exit, not the decision.
+// The word of the NEXT round's survivor is requested before this round's append (one LDS round trip per round would otherwise sit on the chain):
+// 11 vector + 6 scalar + 2 LDS instructions per round against 7 + 5 + 1.
+DEVFN void compact_rounds_res_e(uint32_t &mask, uint32_t tag, uint32_t &qbyte, uint32_t qfull, uint32_t kbase, uint32_t kh1) {
+    unsigned long long save, act;
+    uint32_t t, lz, ent, bm, c, ka, kn, d;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmpx_ne_u32_e32 vcc, 0, %[mask]\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "v_ffbh_u32 %[lz], %[mask]\n\t"
+        "v_lshl_add_u32 %[ka], %[lz], 2, %[kbase]\n\t"
+        "ds_read_b32 %[kn], %[ka]\n\t"
+        "1:\n\t"
+        "v_add_u32 %[ent], %[tag], %[lz]\n\t"
+        "v_lshrrev_b32 %[bm], %[lz], %[top]\n\t"
+        "v_xor_b32 %[mask], %[mask], %[bm]\n\t"
+        "v_ffbh_u32 %[lz], %[mask]\n\t"
+        "v_lshl_add_u32 %[ka], %[lz], 2, %[kbase]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_u32 %[d], %[kn], %[kh1]\n\t"
+        "ds_read_b32 %[kn], %[ka]\n\t"
+        "v_cmp_lt_u32_e32 vcc, 2, %[d]\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[qb]\n\t"
+        "s_bcnt1_i32_b64 %[c], vcc\n\t"
+        "s_and_saveexec_b64 %[act], vcc\n\t"
+        "ds_write_b32 %[t], %[ent]\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "s_lshl2_add_u32 %[qb], %[c], %[qb]\n\t"
+        "v_cmpx_ne_u32_e32 vcc, 0, %[mask]\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "s_cmp_lt_u32 %[qb], %[qf]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "2:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [mask] "+v"(mask), [qb] "+s"(qbyte), [t] "=&v"(t), [lz] "=&v"(lz), [ent] "=&v"(ent), [bm] "=&v"(bm), [c] "=&s"(c), [save] "=&s"(save), [act] "=&s"(act),
+          [ka] "=&v"(ka), [kn] "=&v"(kn), [d] "=&v"(d)
+        : [tag] "v"(tag), [top] "s"(0x80000000u), [qf] "s"(qfull), [kbase] "v"(kbase), [kh1] "v"(kh1)
         : "vcc", "scc", "memory");
 }
 
@@ -242,7 +298,7 @@ DEVFN ExactRegs exact_issue_e(const WaveLdsE &w, const Sorted &so, uint32_t qoff
 // CHUNK == 1: the hole-free sequence of small inputs -- no block allocator, the batch's records go to the wave's staging buffer (sg) on the
 // general path, and a pair a probe has to decide is decided HERE, by the lane that holds it (classify<true>, as k_patch_deferred does per
 // list entry): these kernels run at two waves per SIMD anyway, the probes' registers cost them nothing, and a call without a probe pass is
-// one launch shorter.  pe: the bounds the probes read (DIRECT only).
+// one launch shorter.  pe: the bounds the probes read (DIRECT only) + the clash / covalent bounds of the full level count (global memory).
 struct ProbeParamsE { const double *s_clash, *s_cov, *s_vdw, *s_hacc; double s_ion, s_polar, s_hphob; };
 template <bool FULL, bool ONLY, uint32_t CHUNK>
 DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, uint32_t count, uint32_t slot0,
@@ -290,7 +346,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
         if (!DIRECT) a_old = alloc_issue_e(bl.alloc_state, n_rec);
     }
     // distance levels: Le against the element pair's bounds {vdw, cov, clash}, Lg against the fixed ones {4.5, 4.0, 3.5}; L = 4 Le + Lg.
-    // All candidates (!ONLY): only the van-der-Waals bound on the common path -- a distance below the covalent or the clash bound of ITS
+    // Only the van-der-Waals bound on the common path -- a distance below the covalent or the clash bound of ITS
     // element pair is first of all below the largest covalent bound of any pair (K.s_cov_max, a scalar), which hardly any candidate is
     // (the atoms of one residue and of sequence neighbours never pair, complex.rs:108-113); those batches recompute the levels in full on
     // the general path below.  Two LDS reads and four half-rate vector instructions less per batch.
@@ -299,7 +355,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
     uint32_t L = 0;
     lmask m_close = 0ull;
     auto levels_full = [&]() {
-        const double t_clash = tb.s_clash[eix], t_cov = tb.s_cov[eix];
+        const double t_clash = pe.s_clash[eix], t_cov = pe.s_cov[eix];  // (global memory, 2 x 2 KB that sit in the vector L1: rare path)
         uint32_t Lf = 0;
         asm("v_cmp_lt_f64_e32 vcc, %[s], %[tv]\n\t"
             "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
@@ -319,9 +375,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
             : "vcc");
         return Lf;
     };
-    if (ONLY) {
-        L = levels_full();
-    } else {
+    {
         asm("v_cmp_lt_f64_e32 vcc, %[s], %[tv]\n\t"
             "v_addc_co_u32_e32 %[L], vcc, 0, %[L], vcc\n\t"
             "v_lshlrev_b32_e32 %[L], 2, %[L]\n\t"
@@ -336,6 +390,9 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
             : "vcc");
         m_close = lm_gt_f64_sv(K.s_cov_max, s) & m_valid;
     }
+    // contacts only: the record count depends on the kinds, so a batch with a candidate inside some covalent band counts its levels in full right
+    // here (a wave-uniform branch, hardly ever taken)
+    if (ONLY && m_close) { L = levels_full(); m_close = 0ull; }
     // W = (Pa & Qb) | (Pb & Qa): P is byte 1 of the pair word, Q byte 2
     uint32_t w1, w2;
     asm("v_and_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
@@ -458,7 +515,9 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
 // no holes and the launch sequence no fix-up kernel (stage_flush_e above; engine.cpp finish_result)
 struct StageLdsE { uint4 rec[4][kStageRecords]; uint32_t wave_n[4]; unsigned long long base; };
 struct NoStageLdsE { uint4 rec[1][1]; uint32_t wave_n[1]; unsigned long long base; };
-template <int WAVES, int SPLIT, bool ONLY, bool DIRECT = false>
+// RES: the residue rule is applied to every prefilter survivor before it is queued (compact_rounds_res_e) -- the launcher's choice for inputs whose
+// residues are runs of atoms; the result is the same list either way
+template <int WAVES, int SPLIT, bool ONLY, bool DIRECT = false, bool RES = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
                                                                                            EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     // Inputs that do not fill the chip emit a few thousand records per block, or a few hundred: a 4096-record chunk per block would leave
@@ -469,13 +528,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     static_assert(!DIRECT || WAVES == 4, "the hole-free sequence is the 4-wave kernels'");
     constexpr uint32_t kChunkE = DIRECT ? 1u : (SPLIT == 4 ? kSmallChunkRecords : kChunkRecords);
     static_assert(DIRECT || WAVES == kEWaves, "the 4-wave kernels are DIRECT");
+    static_assert(!(RES && DIRECT), "the residue-rule rounds are the 12-wave kernels'");
     __shared__ TablesE tb;
-    __shared__ WaveLdsE wl[WAVES];
+    __shared__ typename std::conditional<RES, WaveLdsR, WaveLdsN>::type wl[WAVES];
     __shared__ BlockLds bl;
     __shared__ typename std::conditional<DIRECT, StageLdsE, NoStageLdsE>::type stg;
     // (the grid and parameter words first: their loads travel together with the table's instead of behind the barrier)
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
     const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
+    const uint32_t rk_off = RES ? gp->rk_bad : 0u;  // (wave-uniform) an ordinal or a chain rank did not fit the residue words: no early rejection
     const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar, dprm->s_cov_max};
     const double r2m = gp->r2m;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -501,9 +562,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     // chunks that lie wholly inside the caller's buffer: a batch placed in one of them needs no further capacity test (exact_finish_e's fast tail)
     // (and inside its first 2^32 bytes: the fast path addresses with a 32-bit byte offset; what lies beyond takes the general path)
     const uint32_t cap_chunks = (uint32_t)min(tg.capacity >> chunk_shift_of(kChunkE), (unsigned long long)((1u << 28) / kChunkE));
-    WaveLdsE &w = wl[wave];
+    WaveLdsE &w = wl[wave].e;
+    uint32_t nkey_lds = 0;  // RES: LDS byte address of the staged chunk's residue words
+    if constexpr (RES) nkey_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)wl[wave].nkey);
     StageRef sg{stg.rec[DIRECT ? wave : 0u], 0u};
-    const ProbeParamsE pe{tb.s_clash, tb.s_cov, tb.s_vdw, dprm->s_hacc, K.s_ion, K.s_polar, K.s_hphob};
+    const ProbeParamsE pe{dprm->s_clash, dprm->s_cov, tb.s_vdw, dprm->s_hacc, K.s_ion, K.s_polar, K.s_hphob};
     // task distribution as in k_pairs: block group (b mod 8) = one XCD = one contiguous eighth of the tasks, static first task per wave
     const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
     const uint32_t g_lo = (uint32_t)(((unsigned long long)n_tasks * group) / n_groups), g_hi = (uint32_t)(((unsigned long long)n_tasks * (group + 1u)) / n_groups);
@@ -521,6 +584,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
         const bool have = a < n_heavy;
         float4 home = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t cx = 0, cy = 0, cz = 0;
+        uint32_t kh1 = kRkOff;  // RES: the home atom's residue word - 1
         wave_lds_fence();  // the previous task's batches are done with the home records
         {
             u32x4 hxy = {0u, 0u, 0u, 0u}, hzp = {0u, 0u, 0u, 0u};
@@ -532,6 +596,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
                 hxy = u32x4{(uint32_t)__double2loint(fx), (uint32_t)__double2hiint(fx), (uint32_t)__double2loint(fy), (uint32_t)__double2hiint(fy)};
                 hzp = u32x4{(uint32_t)__double2loint(fz), (uint32_t)__double2hiint(fz), f.pw, f.orig};
                 hkey = ((unsigned long long)f.crm << 32) | f.res_ord;
+                if (RES && !rk_off) kh1 = ((f.crm & kRkChainMax) << kRkOrdBits) + (f.res_ord & ((1u << kRkOrdBits) - 1u)) - 1u;
                 const uint32_t c = f.cell;
                 cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
             }
@@ -584,6 +649,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
                     static_assert(kEChunk == 128u, "two staging loads per lane");
                     const uint32_t p0 = min(cs + lane, ce - 1u), p1 = min(cs + lane + 64u, ce - 1u);
                     const float4 r0 = so.rec[p0], r1 = so.rec[p1];
+                    if constexpr (RES) {
+                        const uint32_t k0 = so.rkey[p0], k1 = so.rkey[p1];
+                        wl[wave].nkey[lane] = k0; wl[wave].nkey[lane + 64u] = k1;
+                    }
                     w.nrec[lane] = r0; w.nrec[lane + 64u] = r1;
                 }
                 wave_lds_fence();
@@ -627,16 +696,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
                     const uint32_t rem = min(len > acc0 ? len - acc0 : 0u, 32u);
                     mask = (mask << (32u - nacc)) & (uint32_t)(0xFFFFFFFF00000000ull >> rem);
                     const uint32_t tag = lane_tag + (cs + off + acc0);  // (bit 31 - lz <-> test q = lz <-> neighbour slot cs + off + acc0 + q)
+                    const uint32_t kbase = nkey_lds + 4u * (off + acc0);  // RES: ... <-> residue word nkey[off + acc0 + q]
+                    auto compact = [&](uint32_t &qb) {
+                        if constexpr (RES) compact_rounds_res_e(mask, tag, qb, queue_lds + 256u, kbase, kh1);
+                        else compact_rounds_e(mask, tag, qb, queue_lds + 256u);
+                    };
                     {
                         uint32_t qb = __builtin_amdgcn_readfirstlane(qbyte);  // (wave-uniform by construction: say so)
-                        compact_rounds_e(mask, tag, qb, queue_lds + 256u);
+                        compact(qb);
                         while (qb >= queue_lds + 256u) {  // a full batch: the 64 entries at the tail; then the rest of the run's survivors
                             qb -= 256u;
                             // (Finishing the batch only after the next compaction rounds -- the gathers in flight meanwhile -- was measured: no
                             // gain, 162 us either way; the compiler then parks the next prefilter run on vmcnt(0) for a register it sees reused.)
                             const ExactRegs g = exact_issue_e<true>(w, so, qb - queue_lds, 64u, lane);
                             exact_finish_e<true, ONLY, kChunkE>(g, K, tb, w, bl, 64u, slot0, tg, cap_chunks, result, lane, wflags, probe_bits, sg, in, so, pe);
-                            compact_rounds_e(mask, tag, qb, queue_lds + 256u);
+                            compact(qb);
                         }
                         qbyte = qb;
                     }
@@ -673,7 +747,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
 
 // single-pass emit + hole fix-up: leaves result[0] = number of pairs, out[0..P) contiguous
 bool launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigned long long capacity, hipStream_t st, Profiler *prof, bool contacts_only,
-                   bool skip_deferred) {
+                   bool skip_deferred, bool res_filter) {
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t tasks = (in.n + 63u) / 64u;
     // Fewer tasks than the chip has wave slots: every task is shared out over four waves by window kind (eight for the smallest inputs, two
@@ -690,16 +764,18 @@ bool launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
     if (prof) prof->begin("pairs_emit", st);
 #define ARP_LAUNCH_E(W, S, O, ...) hipLaunchKernelGGL((k_emit<W, S, O, ##__VA_ARGS__>), dim3(nb), dim3(W * 64), 0, st, in, (const GridParams *)ws.grid, (const DevParams *)ws.params, \
                                                  (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
+    // res_filter: the residue-rule kernels (the engine asks for them when the input's residues are runs of atoms, and had k_place write the residue
+    // words); the 4-wave kernels of the smallest inputs have no such variant (a call of that size is launches and round trips, not batches)
     if (contacts_only) {
         if (eight) ARP_LAUNCH_E(4, 8, true, true);
         else if (narrow) ARP_LAUNCH_E(4, 4, true, true);
-        else if (shared) ARP_LAUNCH_E(kEWaves, 4, true);
-        else ARP_LAUNCH_E(kEWaves, 1, true);
+        else if (shared) { if (res_filter) ARP_LAUNCH_E(kEWaves, 4, true, false, true); else ARP_LAUNCH_E(kEWaves, 4, true); }
+        else { if (res_filter) ARP_LAUNCH_E(kEWaves, 1, true, false, true); else ARP_LAUNCH_E(kEWaves, 1, true); }
     } else {
         if (eight) ARP_LAUNCH_E(4, 8, false, true);
         else if (narrow) ARP_LAUNCH_E(4, 4, false, true);
-        else if (shared) ARP_LAUNCH_E(kEWaves, 4, false);
-        else ARP_LAUNCH_E(kEWaves, 1, false);
+        else if (shared) { if (res_filter) ARP_LAUNCH_E(kEWaves, 4, false, false, true); else ARP_LAUNCH_E(kEWaves, 4, false); }
+        else { if (res_filter) ARP_LAUNCH_E(kEWaves, 1, false, false, true); else ARP_LAUNCH_E(kEWaves, 1, false); }
     }
 #undef ARP_LAUNCH_E
     launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, direct ? 1u : (shared ? kSmallChunkRecords : kChunkRecords));

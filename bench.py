@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-check", action="store_true", help="diagnostic (ablation) builds: do not assert the pair count")
     ap.add_argument("--deterministic", action="store_true", help="two-pass ordered emitter (ARP_FLAG_DETERMINISTIC)")
+    ap.add_argument("--residue-runs", choices=["auto", "on", "off"], default="auto",
+                    help="diagnostic: force (on) or rule out (off) the residue-rule kernels (ARP_FLAG_RESIDUE_RUNS / ARP_FLAG_NO_RESIDUE_RUNS); "
+                         "auto = the engine's memo (a sample of the previous call's atoms), which is what a caller gets")
     ap.add_argument("--contacts-only", action="store_true",
                     help="informational: ARP_FLAG_CONTACTS_ONLY (what the table path runs); `value` then counts emitted contacts, not the headline metric")
     return ap.parse_args()
@@ -267,7 +270,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only)
+    prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only,
+                            residue_runs={"auto": None, "on": True, "off": False}[args.residue_runs])
     check = not args.no_check
 
     recs = {}  # (workload, atoms) -> the generated records (the SAP leg reuses the S1 clouds)

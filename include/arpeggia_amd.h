@@ -101,6 +101,14 @@ typedef struct arp_atoms {
  * with more than ~16 probe candidates per atom -- is grown by arp_contacts_atomic_result and the call run again; it then returns only after
  * the repeat, and what ran on the stream in between has seen an incomplete list.  ARP_FLAG_DETERMINISTIC never speculates.) */
 #define ARP_FLAG_NO_SPECULATION 0x4u
+/* RESIDUE_RUNS / NO_RESIDUE_RUNS: a hint about the input, never a change of the result.  The reference never pairs two atoms of one residue or
+ * of sequence neighbours in one chain (complex.rs:108-113); in an input whose residues are runs of atoms (every protein) a third of an atom's
+ * geometric neighbours are such atoms, and the single-pass emitter has kernels that drop them before the exact phase.  They cost a little on an
+ * input of one-atom residues (a synthetic cloud), so the engine picks them from a sample of the PREVIOUS call's atoms on the same context
+ * (how many of the first 255 atoms continue their predecessor's residue).  RESIDUE_RUNS asks for them outright (a first call, mixed workloads),
+ * NO_RESIDUE_RUNS rules them out.  Both kernels emit the same list. */
+#define ARP_FLAG_RESIDUE_RUNS 0x8u
+#define ARP_FLAG_NO_RESIDUE_RUNS 0x10u
 
 typedef struct arp_params {
     double vdw_comp;             /* mod.rs:61 vdw_comp    (default 0.1) */

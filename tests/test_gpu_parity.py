@@ -258,6 +258,43 @@ def test_synthetic_clouds_vs_oracle(ctx, gen, n):
     assert_pairs_equal(got, want, f"{gen} {n}")
 
 
+def test_residue_rule_kernels_emit_the_same_lists(ctx):
+    """Round 5: k_emit<.., RES> drops prefilter survivors of the home atom's own residue and of its sequence neighbours (complex.rs:108-113)
+    BEFORE the exact phase, on one 32-bit residue word per atom (chain rank << 20 | ordinal).  The early exit must never change the list:
+    asked for (ARP_FLAG_RESIDUE_RUNS), ruled out (ARP_FLAG_NO_RESIDUE_RUNS) and chosen by the engine's memo, against the oracle, with all
+    candidates and contacts only, on the sizes that select the 12-wave kernels (task split 4 and 1), with hydrogens (the deferred probes),
+    and on inputs whose ordinals / chain ranks do not fit the word (the rule is then switched off on the device)."""
+    cases = []
+    for n in (30000, 330000):  # 12-wave kernels with the four-way task split / without
+        rec = synth.gen_s1(n)
+        soa = aa.Structure.from_records(rec, hierarchy=True).soa("/")
+        want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True).atomic_contacts()
+        cases.append((f"s1 {n}", soa, want))
+    rec = synth.gen_stress(n_res=5000, seed=77, box=28.0 * (5000 / 400.0) ** (1.0 / 3.0))
+    cases.append(("hydrogen-rich", aa.Structure.from_records(rec).soa("/"), ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False).atomic_contacts()))
+    rec = synth.gen_s2(40000)  # one-atom residues, ordinals 2 i: nothing to reject
+    cases.append(("s2 40000", aa.Structure.from_records(rec, hierarchy=True).soa("/"), ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True).atomic_contacts()))
+    for what, soa, want in cases:
+        for runs in (True, False, None):
+            for only in (False, True):
+                got = ctx.atomic_contacts(soa, aa.default_params(contacts_only=only, residue_runs=runs))
+                assert_pairs_equal(got, want[want["kind"] != 0] if only else want, f"{what} residue_runs={runs} only={only}")
+    # the word's limits: ordinals up to 2^20 - 3 fit (and the last residue of a chain is still 3 words from the first of the next); one more and
+    # k_place flags the input, which switches the early exit off -- the lists stay the same either way
+    what, soa, want = cases[0]
+    top = int(soa["res_ord"].max())
+    for shift in ((1 << 20) - 3 - top, (1 << 20) - 2 - top, 1 << 30):
+        moved = dict(soa); moved["res_ord"] = (soa["res_ord"] + np.uint32(shift)).astype(np.uint32)
+        assert_pairs_equal(ctx.atomic_contacts(moved, aa.default_params(residue_runs=True)), want, f"{what} ordinals + {shift}")
+    for first in (2047 - int(soa["chain_rank"].max()), 2048, 1 << 31):  # chain ranks: 11 bits fit
+        moved = dict(soa); moved["chain_rank"] = (soa["chain_rank"] + np.uint32(max(first, 0))).astype(np.uint32)
+        assert_pairs_equal(ctx.atomic_contacts(moved, aa.default_params(residue_runs=True)), want, f"{what} chain ranks + {first}")
+    # the memo: a fresh context runs the plain kernels first, samples the input in k_place, and picks the residue-rule kernels from the second call on
+    fresh = aa.Context(0)
+    for k in range(3):
+        assert_pairs_equal(fresh.atomic_contacts(soa), want, f"{what} memo call {k}")
+
+
 # ---------------------------------------------------------------------------------------------- edge cases
 def _mini(xyz, names=None, resn=None, elems=None, chains=None, resi=None):
     n = len(xyz)
@@ -392,8 +429,10 @@ def test_s1_cloud_1e6_vs_oracle(ctx):
     soa = prod.soa("/")
     want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True).atomic_contacts()
     assert len(want) > 15_000_000
-    got = ctx.atomic_contacts(soa)
+    got = ctx.atomic_contacts(soa, aa.default_params(residue_runs=False))
     assert_pairs_equal(got, want, "s1 1e6")
+    got = ctx.atomic_contacts(soa, aa.default_params(residue_runs=True))  # (round 5: the residue rule applied before the exact phase)
+    assert_pairs_equal(got, want, "s1 1e6, residue-rule kernels")
     only = ctx.atomic_contacts(soa, aa.default_params(contacts_only=True))
     assert_pairs_equal(only, want[want["kind"] != 0], "s1 1e6 contacts only")
     del got, only
@@ -616,7 +655,7 @@ def test_config5_batch_every_member_matches_the_oracle(ctx):
     ctx2 = aa.Context(0)  # a second context on the same device stands in for a second GPU: the longest-first deal over devices
     for det in (False, True):
         for only in (False, True):
-            prm = aa.default_params(deterministic=det, contacts_only=only)
+            prm = aa.default_params(deterministic=det, contacts_only=only, residue_runs=None if det else only)  # (the pack through both kernel families)
             for contexts in ([ctx], [ctx, ctx2]):
                 got = aa.atomic_contacts_batch(contexts, views, prm)          # packed: shared launches, split on the device
                 assert len(got) == len(views)
