@@ -119,6 +119,7 @@ def _load():
     vp = C.c_void_p
     sig = {
         "arp_api_version": (C.c_int32, []),
+        "arp_check_api_version": (C.c_int32, [C.c_int32]),
         "arp_strerror": (C.c_char_p, [C.c_int32]),
         "arp_last_error": (C.c_char_p, []),
         "arp_device_count": (C.c_int32, []),

@@ -213,6 +213,12 @@ def atoms_from_arrays(soa: dict, location: int = _lib.ARP_MEM_HOST, keep: list |
         if a is None:
             return None
         if hasattr(a, "data_ptr"):
+            # a device tensor is handed over as a raw address: its element size and layout are all that can be checked here, and they must be
+            # what arp_atoms declares (API v2: 32-bit chain ranks and models -- a v1-style int16 tensor would be read 4 bytes per atom)
+            want = np.dtype(dtype).itemsize
+            if a.element_size() != want or not a.is_contiguous():
+                raise ArpeggiaError(_lib.ARP_ERR_BAD_INPUT, f"arp_atoms.{name}: needs a contiguous tensor of {want}-byte elements ({dtype}), "
+                                    f"got element size {a.element_size()}, contiguous={a.is_contiguous()}")
             if keep is not None:
                 keep.append(a)
             return a.data_ptr() if a.numel() else None

@@ -48,29 +48,34 @@ __global__ __launch_bounds__(1024) void k_pack_scan(uint32_t K, const uint32_t *
     __shared__ uint32_t part[1024];
     const uint32_t per = (K + 1023u) / 1024u, lo = min(K, threadIdx.x * per), hi = min(K, lo + per);
     uint32_t s = 0;
-    for (uint32_t m = lo; m < hi; m++) s += min(n_models[m], 0x10000u);  // (saturating: a member with 2^32 - 1 models must not wrap the total back into range)
+    for (uint32_t m = lo; m < hi; m++) s = min(s + min(n_models[m], kPackModels), 2u * kPackModels);  // (saturating: a member with 2^32 - 1 models must not wrap the total back into range)
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (uint32_t t = 0; t < 1024u; t++) { const uint32_t v = part[t]; part[t] = run; run += v; }
+        for (uint32_t t = 0; t < 1024u; t++) { const uint32_t v = part[t]; part[t] = run; run = min(run + v, 2u * kPackModels); }  // (saturating: 1024 parts of up to 2^16 each would still fit, 2^32 - 1 per member would not)
         desc[K].model_off = run;
-        status[0] = run > 65535u ? 1u : 0u;
+        status[0] = run > kPackModels - 1u ? 1u : 0u;
     }
     __syncthreads();
     uint32_t run = part[threadIdx.x];
     for (uint32_t m = lo; m < hi; m++) { desc[m].model_off = run; run += n_models[m]; }
 }
 
-// renumber in place: models and residue ids per atom, hydrogen-list offsets and CB / SG atom indices per residue, atom indices per hydrogen
-__global__ __launch_bounds__(256) void k_pack_fix(uint32_t n, uint32_t n_res, uint32_t n_h, uint32_t K, const PackDesc *desc, uint32_t *model, uint32_t *res_id,
-                                                  uint32_t *res_h_ptr, uint32_t *res_cb, uint32_t *res_sg, uint32_t *res_h_idx) {
+// renumber in place: models and residue ids per atom, hydrogen-list offsets and CB / SG atom indices per residue, atom indices per hydrogen.
+// A pack whose models do not fit the per-model tables of the workspace (status[0] != 0: more than 65535 in all, or one member with a sparse id
+// such as 70 000) is re-run member by member by the host, which only learns of it after the stream has run -- so the kernels that follow must
+// stay in bounds whatever the members hold: every atom of such a pack gets model 0 (API v1's 16-bit ordinals could not leave the tables; v2's
+// 32-bit ones can -- ADVICE r4).
+__global__ __launch_bounds__(256) void k_pack_fix(uint32_t n, uint32_t n_res, uint32_t n_h, uint32_t K, const PackDesc *desc, const uint32_t *status, uint32_t *model,
+                                                  uint32_t *res_id, uint32_t *res_h_ptr, uint32_t *res_cb, uint32_t *res_sg, uint32_t *res_h_idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool overfull = status[0] != 0u;  // (written by k_pack_scan, the previous launch on this stream)
     OwnerCache oc;
     const uint32_t own = lane_owner(desc, K, i, i < n, oc);
     if (i < n) {
         const PackDesc d = desc[own];
-        model[i] = model[i] + d.model_off;
+        model[i] = overfull ? 0u : min(model[i] + d.model_off, kPackModels - 1u);  // (the sum is below kPackModels when the pack is not overfull)
         res_id[i] += d.first_res;
     }
     if (i < n_res) {
@@ -218,8 +223,8 @@ void launch_pack_fix(const PackArrays &pa, hipStream_t st) {
     (void)hipMemsetAsync(pa.n_models, 0, sizeof(uint32_t) * pa.K, st);
     hipLaunchKernelGGL(k_pack_models, dim3((pa.n + 255u) / 256u), dim3(256), 0, st, pa.n, pa.K, (const PackDesc *)pa.desc, (const uint32_t *)pa.model, pa.n_models);
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pa.K, (const uint32_t *)pa.n_models, pa.desc, pa.status);
-    hipLaunchKernelGGL(k_pack_fix, dim3(nb ? nb : 1u), dim3(256), 0, st, pa.n, pa.n_res, pa.n_h, pa.K, (const PackDesc *)pa.desc, pa.model, pa.res_id, pa.res_h_ptr, pa.res_cb,
-                       pa.res_sg, pa.res_h_idx);
+    hipLaunchKernelGGL(k_pack_fix, dim3(nb ? nb : 1u), dim3(256), 0, st, pa.n, pa.n_res, pa.n_h, pa.K, (const PackDesc *)pa.desc, (const uint32_t *)pa.status, pa.model, pa.res_id,
+                       pa.res_h_ptr, pa.res_cb, pa.res_sg, pa.res_h_idx);
 }
 void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, bool ordered, hipStream_t st) {
     (void)hipMemsetAsync(pa.count, 0, sizeof(unsigned long long) * pa.K, st);

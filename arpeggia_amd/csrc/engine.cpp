@@ -1230,6 +1230,12 @@ extern "C" int32_t arp_profile_read(arp_context *ctx, const char **names, float 
 
 // ---- library-level -----------------------------------------------------------------------------------------------
 extern "C" int32_t arp_api_version(void) { return ARP_API_VERSION; }
+extern "C" arp_status arp_check_api_version(int32_t header_version) {
+    if (header_version == ARP_API_VERSION) return ARP_OK;
+    set_error("API version mismatch: the caller was compiled against version %d of arpeggia_amd.h, the library implements version %d "
+              "(v2: arp_atoms.chain_rank and arp_atoms.model are uint32_t)", (int)header_version, (int)ARP_API_VERSION);
+    return ARP_ERR_BAD_INPUT;
+}
 extern "C" const char *arp_last_error(void) { return g_err; }
 extern "C" const char *arp_strerror(arp_status s) {
     switch (s) {

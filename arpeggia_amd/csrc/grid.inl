@@ -152,6 +152,7 @@ __global__ __launch_bounds__(kBoundsThreads) void k_bounds(DevAtoms in, double *
 // the atoms).  The members of a pack are contiguous, so a wave is almost always inside one model: six wave reductions, six atomics.
 DEVFN uint32_t f32_code(float f) { const uint32_t u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
 DEVFN float f32_decode(uint32_t c) { return __uint_as_float((c >> 31) ? (c & 0x7FFFFFFFu) : ~c); }
+constexpr uint32_t kPackModels = 65536;  // entries of Workspace::model_box / model_org: every index into them is clamped to this
 __global__ __launch_bounds__(256) void k_model_box_init(uint32_t *box) {  // {min xyz = +inf code, max xyz = -inf code} per model
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     box[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void k_model_bounds(DevAtoms in, uint32_t *box
     const bool use = i < in.n && !(in.attr[i] & ARP_ATTR_H);
     uint32_t m = ARP_NONE, lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
     if (use) {
-        m = in.model[i];
+        m = min(in.model[i], kPackModels - 1u);  // (k_pack_fix keeps a pack's ordinals below this; the clamp is the table's own guard)
         const double p[3] = {in.x[i], in.y[i], in.z[i]};
         for (int k = 0; k < 3; k++) { lo[k] = f32_code(__double2float_rd(p[k])); hi[k] = f32_code(__double2float_ru(p[k])); }
     }
@@ -213,8 +214,9 @@ DEVFN void setup_block(BoxAcc &acc, SetupLds &l, bool publish, GridParams *g, De
     // Packed batch: the grid is sized by the LARGEST member and every model gets its own origin (its box's min corner) and
     // its own midpoint for the f32 records -- members may sit anywhere in space without inflating the cell count.
     double ext[3] = {0.0, 0.0, 0.0};
+    const uint32_t box_models = min(acc.models, kPackModels);  // (the per-model tables hold kPackModels entries)
     if (model_box) {  // (differences of f32 values are exact in f64)
-        for (uint32_t m = threadIdx.x; m < acc.models; m += blockDim.x) {
+        for (uint32_t m = threadIdx.x; m < box_models; m += blockDim.x) {
             const uint32_t *b = model_box + 6u * m;
             if (b[0] == 0xFFFFFFFFu) continue;  // no heavy atom in this model
             for (int k = 0; k < 3; k++) ext[k] = fmax(ext[k], (double)f32_decode(b[3 + k]) - (double)f32_decode(b[k]));
@@ -225,7 +227,7 @@ DEVFN void setup_block(BoxAcc &acc, SetupLds &l, bool publish, GridParams *g, De
         __syncthreads();
         for (int k = 0; k < 3; k++) ext[k] = fmax(fmax(l.ext[0][k], l.ext[1][k]), fmax(l.ext[2][k], l.ext[3][k]));
         if (publish)
-            for (uint32_t m = threadIdx.x; m < acc.models; m += blockDim.x) {
+            for (uint32_t m = threadIdx.x; m < box_models; m += blockDim.x) {
                 const uint32_t *b = model_box + 6u * m;
                 double *o = model_org + 6u * m;
                 for (int k = 0; k < 3; k++) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void k_setup(const double *partials, uint32_t 
 
 DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uint32_t model) {
     double ox = g.ox, oy = g.oy, oz = g.oz;
-    if (g.model_org) { const double *o = g.model_org + 6u * model; ox = o[0]; oy = o[1]; oz = o[2]; }  // packed batch: the member's own corner
+    if (g.model_org) { const double *o = g.model_org + 6u * min(model, kPackModels - 1u); ox = o[0]; oy = o[1]; oz = o[2]; }  // packed batch: the member's own corner
     double fx = (x - ox) * g.inv_edge_x, fy = (y - oy) * g.inv_edge, fz = (z - oz) * g.inv_edge;
     uint32_t cx = (fx >= 0.0) ? (uint32_t)fmin(fx, 4.0e9) : 0u;  // NaN -> 0
     uint32_t cy = (fy >= 0.0) ? (uint32_t)fmin(fy, 4.0e9) : 0u;
@@ -504,7 +506,7 @@ DEVFN uint32_t make_pair_word(uint32_t attr, bool res_has_h) {
 DEVFN void place_atom(const DevAtoms &in, const GridParams *gp, const Sorted &so, uint32_t i, uint32_t c, uint32_t d) {
     const double x = in.x[i], y = in.y[i], z = in.z[i];
     double mx = gp->mx, my = gp->my, mz = gp->mz;
-    if (gp->model_org) { const double *o = gp->model_org + 6u * (uint32_t)in.model[i] + 3u; mx = o[0]; my = o[1]; mz = o[2]; }
+    if (gp->model_org) { const double *o = gp->model_org + 6u * min((uint32_t)in.model[i], kPackModels - 1u) + 3u; mx = o[0]; my = o[1]; mz = o[2]; }
     const float fx = (float)(x - mx), fy = (float)(y - my), fz = (float)(z - mz);
     const float4 rv = make_float4(fx, fy, fz, (float)((double)fx * fx + (double)fy * fy + (double)fz * fz));
     so.rec[d] = rv;
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void k_place(DevAtoms in, GridParams *gp, cons
         h0[u] = h1[u] = 0u;
         if (any_h) { h0[u] = in.res_h_ptr[rid[u]]; h1[u] = in.res_h_ptr[rid[u] + 1u]; }
         mx[u] = gmx; my[u] = gmy; mz[u] = gmz;
-        if (morg) { const double *o = morg + 6u * md[u] + 3u; mx[u] = o[0]; my[u] = o[1]; mz[u] = o[2]; }  // packed batch: the member's own midpoint
+        if (morg) { const double *o = morg + 6u * min(md[u], kPackModels - 1u) + 3u; mx[u] = o[0]; my[u] = o[1]; mz[u] = o[2]; }  // packed batch: the member's own midpoint
     }
 #pragma unroll
     for (uint32_t u = 0; u < kPlacePer; u++) {

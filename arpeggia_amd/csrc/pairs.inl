@@ -665,7 +665,7 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
     const uint32_t nbb = (n + kBoundsThreads - 1u) / kBoundsThreads, bb = nbb < 1 ? 1 : (nbb < kBoundsBlocks ? nbb : kBoundsBlocks);
     if (!all_atoms) hipLaunchKernelGGL(k_bounds, dim3(bb), dim3(kBoundsThreads), 0, st, in, ws.partials);
     if (in.per_model && n) {
-        hipLaunchKernelGGL(k_model_box_init, dim3(65536u * 6u / 256u), dim3(256), 0, st, ws.model_box);
+        hipLaunchKernelGGL(k_model_box_init, dim3(kPackModels * 6u / 256u), dim3(256), 0, st, ws.model_box);
         hipLaunchKernelGGL(k_model_bounds, dim3(nb), dim3(256), 0, st, in, ws.model_box);
     }
     if (!fold) hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, (const double *)ws.partials, bb, ws.grid, ws.params, cutoff, ws.ncells_cap, n, ws.result,

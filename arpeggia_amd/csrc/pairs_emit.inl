@@ -148,12 +148,15 @@ DEVFN void compact_rounds_res_e(uint32_t &mask, uint32_t tag, uint32_t &qbyte, u
         "v_lshl_add_u32 %[ka], %[lz], 2, %[kbase]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_sub_u32 %[d], %[kn], %[kh1]\n\t"
-        "ds_read_b32 %[kn], %[ka]\n\t"
         "v_cmp_lt_u32_e32 vcc, 2, %[d]\n\t"
+        // (gfx9 hazard, "mixed use of VCC": a VALU instruction that reads vcc as a CONSTANT needs one wait state after the VALU compare that
+        // wrote it, and nothing inserts it inside inline assembly -- v_mbcnt_lo right behind the compare ranked the lanes on the previous
+        // round's mask.  The plain rounds get their wait state from the branch between v_cmpx and v_mbcnt_lo.)
+        "ds_read_b32 %[kn], %[ka]\n\t"
+        "s_bcnt1_i32_b64 %[c], vcc\n\t"
         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
         "v_lshl_add_u32 %[t], %[t], 2, %[qb]\n\t"
-        "s_bcnt1_i32_b64 %[c], vcc\n\t"
         "s_and_saveexec_b64 %[act], vcc\n\t"
         "ds_write_b32 %[t], %[ent]\n\t"
         "s_mov_b64 exec, %[act]\n\t"

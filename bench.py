@@ -68,9 +68,7 @@ def to_device(soa, torch, dev):
 
     out = {}
     for k, v in soa.items():
-        if v.dtype == np.uint16:
-            v = v.view(np.int16)
-        elif v.dtype == np.uint32:
+        if v.dtype == np.uint32:
             v = v.view(np.int32)
         out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
     return out

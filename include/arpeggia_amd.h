@@ -142,6 +142,10 @@ typedef struct arp_table arp_table;         /* the 20-column contact table (mod.
 
 /* ---- library / device ---- */
 int32_t arp_api_version(void);
+/* A binder compiled against this header calls arp_check_api_version(ARP_API_VERSION) once: ARP_OK when the library lays out arp_atoms /
+ * arp_params / arp_pair as that version of the header does, ARP_ERR_BAD_INPUT (+ arp_last_error) otherwise -- a v1 caller (16-bit chain
+ * ranks and models) would otherwise hand over arrays the v2 kernels read 4 bytes per atom. */
+arp_status arp_check_api_version(int32_t header_version);
 const char *arp_strerror(arp_status s);
 const char *arp_last_error(void);
 int32_t arp_device_count(void);             /* gfx950 devices visible; 0 => every compute call fails with ARP_ERR_NO_DEVICE */

@@ -20,7 +20,7 @@ rec = synth.gen_stress(n_res=n_res, seed=5, box=box)
 print(f"generated {len(rec['x'])} atoms in {time.perf_counter() - t0:.1f} s (box {box:.0f} A)")
 s = aa.Structure.from_records(rec)
 soa = s.soa("/")
-dev = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda() for k, v in soa.items()}
+dev = {k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda() for k, v in soa.items()}
 keep = []
 atoms = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
 ctx = aa.Context(0, stream=torch.cuda.current_stream().cuda_stream)

@@ -14,7 +14,7 @@ from arpeggia_amd import _lib  # noqa: E402
 for name in ("1ubq", "6bft"):
     s = aa.load_model(str(ROOT / "tests" / "data" / f"{name}.pdb"))
     soa = s.soa("/")
-    dev = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda() for k, v in soa.items()}
+    dev = {k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda() for k, v in soa.items()}
     keep = []
     atoms = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
     stream = torch.cuda.current_stream()

@@ -445,7 +445,7 @@ def test_enqueue_with_resident_buffers_and_capacity_error(ctx):
     prod = aa.load_model(str(synth.DATA / "6bft.pdb"))
     soa = prod.soa("/")
     want = ctx.atomic_contacts(soa)
-    dev = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda() for k, v in soa.items()}
+    dev = {k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda() for k, v in soa.items()}
     keep = []
     atoms = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
     prm = aa.default_params()
@@ -569,7 +569,7 @@ def test_contacts_only_is_the_kind_filter_of_the_full_list(ctx, source):
     assert_pairs_equal(aa.atomic_contacts_batch([ctx], [view, view], aa.default_params(contacts_only=True))[1], want, "packed contacts-only")
     torch = pytest.importorskip("torch")
     soa = prod.soa("/")
-    dev = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda() for k, v in soa.items()}
+    dev = {k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda() for k, v in soa.items()}
     keep = []
     atoms = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
     c2 = aa.Context(0, stream=torch.cuda.current_stream().cuda_stream)
@@ -620,6 +620,33 @@ def test_packed_batch_reports_the_failing_structure(ctx):
             aa.atomic_contacts_batch([ctx], [s.view("/") for s in structs], prm)
         assert e.value.status == _lib.ARP_ERR_BAD_INPUT and "CB" in str(e.value)
         assert len(aa.atomic_contacts_batch([ctx], [structs[0].view("/"), structs[2].view("/")], prm)) == 2
+
+
+def test_packed_batch_with_model_ordinals_beyond_the_pack_tables(ctx):
+    """API v2's 32-bit model ordinals can exceed the 65 536 per-model entries of a pack's tables, and the host only learns of it after
+    the stream has run.  A member with a sparse ordinal (70 000, 2^32 - 1) must leave every kernel of the pack in bounds (k_pack_fix gives an
+    overfull pack's atoms model 0; the tables' indices are clamped), the call must report THAT member's input error, and the others' lists must
+    still be right afterwards."""
+    recs = [synth.gen_s1(1200 + 300 * k, seed=400 + k) for k in range(4)]
+    soas = [aa.Structure.from_records(r, hierarchy=True).soa("/") for r in recs]
+    singles = [ctx.atomic_contacts(s, aa.default_params(contacts_only=True)) for s in soas]
+    for sparse in (70000, 0xFFFFFFFF):
+        bad = dict(soas[1]); bad["model"] = soas[1]["model"].copy(); bad["model"][len(bad["model"]) // 2:] = sparse
+        with pytest.raises(aa.ArpeggiaError) as e:
+            aa.atomic_contacts_batch([ctx], [soas[0], bad, soas[2], soas[3]], aa.default_params(contacts_only=True))
+        assert e.value.status == _lib.ARP_ERR_BAD_INPUT and "model" in str(e.value)
+        got = aa.atomic_contacts_batch([ctx], soas, aa.default_params(contacts_only=True))
+        assert all(np.array_equal(canon(g), canon(w)) for g, w in zip(got, singles))
+    # many members whose models add up past the tables: 40 members x 2000 models each (dense, legal one by one) -> the pack is overfull, the
+    # members run one at a time, every list is right
+    many = []
+    for k in range(40):
+        m = dict(soas[k % 4]); n = len(m["x"])
+        m["model"] = (np.arange(n, dtype=np.uint32) * np.uint32(2000) // np.uint32(n)).astype(np.uint32)
+        many.append(m)
+    want = [ctx.atomic_contacts(m, aa.default_params(contacts_only=True)) for m in many[:4]]
+    got = aa.atomic_contacts_batch([ctx], many, aa.default_params(contacts_only=True))
+    assert all(np.array_equal(canon(got[k]), canon(want[k % 4])) for k in range(40))
 
 
 @pytest.mark.parametrize("kernel", ["gather"])
@@ -734,7 +761,7 @@ def test_deferred_pass_memo_survives_new_content_in_the_same_buffers():
     assert (want_b["kind"] & probe_kinds).any() and not (want_a["kind"] & probe_kinds).any()
 
     def dev_of(v):
-        return torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda()
+        return torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda()
 
     per_atom = ("x", "y", "z", "attr", "res_ord", "chain_rank", "model", "res_id")
     shared = {k: torch.empty_like(dev_of(soa_b[k])) for k in per_atom}
@@ -783,7 +810,7 @@ def test_no_speculation_flag_makes_the_enqueued_list_final_on_the_stream(n_res):
     assert (want_b["kind"] & probe_kinds).any()
 
     def dev_of(v):
-        return torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else (v.view(np.int32) if v.dtype == np.uint32 else v)).cuda()
+        return torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda()
 
     per_atom = ("x", "y", "z", "attr", "res_ord", "chain_rank", "model", "res_id")
     shared = {k: torch.empty_like(dev_of(soa_b[k])) for k in per_atom}
