@@ -5,7 +5,7 @@ contacts(), get_contacts(), load_model(), parse_groups().  Importing this packag
 fails loudly if the HIP extension has not been built -- there is no CPU fallback.
 """
 from .api import (  # noqa: F401
-    ArpeggiaError, Context, Structure, PAIR_DTYPE, TABLE_COLUMNS, atomic_contacts_batch, atoms_from_arrays, contacts, contacts_batch, default_params,
+    ArpeggiaError, Context, Structure, PAIR_DTYPE, TABLE_COLUMNS, atomic_contacts_batch, atoms_from_arrays, contacts, contacts_batch, debug_set, default_params,
     device_count, get_contacts, load_model, parse_groups, sap_neighbor_sum, sap_weight,
 )
 from ._lib import ATTR, INTERACTIONS  # noqa: F401

@@ -118,6 +118,7 @@ def _load():
     L = C.CDLL(str(LIB_PATH))
     vp = C.c_void_p
     sig = {
+        "arp_debug_set": (C.c_int32, [C.c_char_p, C.c_int64]),
         "arp_api_version": (C.c_int32, []),
         "arp_check_api_version": (C.c_int32, [C.c_int32]),
         "arp_strerror": (C.c_char_p, [C.c_int32]),

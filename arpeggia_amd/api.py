@@ -66,6 +66,11 @@ def default_params(vdw_comp: float = 0.1, dist_cutoff: float = 6.5, deterministi
     return p
 
 
+def debug_set(key: str, value: int):
+    """arp_debug_set: the library's diagnostic switches ("timing", "emit_kernel", "defer_entries", "table_host"; include/arpeggia_amd.h)."""
+    _check(lib.arp_debug_set(key.encode(), int(value)))
+
+
 def parse_groups(all_chains, groups: str):
     """utils.rs:71-115 on a throw-away structure with one atom per chain (keeps ONE implementation, in C++)."""
     chains = sorted(set(all_chains))

@@ -14,8 +14,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libarpeggia_amd.so"
 SOURCES = ["kernels.hip", "engine.cpp", "structure.cpp", "table.cpp", "table_dev.hip"]
-HEADERS = ["arp_internal.h", "host_common.h", "grid.inl", "pairs.inl", "pairs_emit.inl", "batch.inl", "sap.inl", "table_dev.h", "../../tests/hosttable/table_host.inl",
-           "../../include/arpeggia_amd.h"]
+HEADERS = ["arp_internal.h", "host_common.h", "debug_knobs.h", "grid.inl", "pairs.inl", "pairs_emit.inl", "batch.inl", "sap.inl", "table_dev.h", "../../include/arpeggia_amd.h"]
+TEST_HEADERS = ["../../tests/hosttable/table_host.inl"]  # only the test library (build_host_table_library) contains it: not part of the product's hash
 STAMP = PKG / "build" / "libarpeggia_amd.sha256"  # hash of every source + the flags the library was last built from
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-result",
          # the kernels aggregate their atomics by hand (one lane per wave / per run); the compiler's own wave aggregation only wraps
@@ -34,7 +34,7 @@ def source_hash(extra: tuple = ()) -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    for f in SOURCES + HEADERS + (TEST_HEADERS if extra else []):
         h.update(f.encode()); h.update((CSRC / f).read_bytes())
     h.update(" ".join(FLAGS + list(extra)).encode())
     return h.hexdigest()

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/arpeggia_amd.h"
+#include "debug_knobs.h"
 
 namespace arp {
 

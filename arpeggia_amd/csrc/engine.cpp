@@ -199,14 +199,11 @@ static arp_status ensure_workspace(arp_context *ctx, uint64_t n) {
     A(w.perm, cap); A(w.slot_cell, cap);
     A(w.sorted.rec, cap + 64); A(w.sorted.fat, cap + 64); A(w.sorted.rkey, cap + 64);
     A(w.task_count, cap / 64 + 2); A(w.task_base, cap / 64 + 2);
-    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 32);  // scan_tmp*: >= kScanBlocks + 1
+    A(w.scan_tmp, 1024 + 1); A(w.scan_tmp64, 1024 + 1); A(w.result, 32 + 1024);  // scan_tmp*: >= kScanBlocks + 1; result: 32 words + the kScanBlocks chunk totals of k_scan_single
     A(w.hole_list, 2048); A(w.task_ctr, kTaskCtrWords); w.scratch_cap = emit_scratch_records(); A(w.scratch, w.scratch_cap);
     A(w.model_box, 65536u * 6u); A(w.model_org, 65536u * 6u);
     w.defer_cap = (uint64_t)ctx->defer_scale * std::max<uint64_t>(16 * cap, 1u << 20) + (1u << 20);  // + one partly used 512-entry chunk per block
-    if (const char *dbg = getenv("ARP_DEBUG_DEFER_ENTRIES")) {  // tests: a tiny list, so that the grow-and-repeat path runs
-        const long v = atol(dbg);
-        if (v > 0) w.defer_cap = (uint64_t)ctx->defer_scale * (uint64_t)v;
-    }
+    if (g_debug.defer_entries > 0) w.defer_cap = (uint64_t)ctx->defer_scale * (uint64_t)g_debug.defer_entries;  // tests: a tiny list, so that the grow-and-repeat path runs
     A(w.defer_list, w.defer_cap);
 #undef A
     w.n_cap = (uint32_t)cap;
@@ -591,7 +588,7 @@ arp_status arp::contacts_atomic_view(arp_context *ctx, const arp_atoms *atoms, c
         if ((s = stage_inputs(ctx, atoms, &d)) != ARP_OK) return s;
         if ((s = upload_params(ctx, params)) != ARP_OK) return s;
         unsigned long long total = 0;
-        const bool timing = getenv("ARP_TIMING") != nullptr;
+        const bool timing = g_debug.timing != 0;
         const auto t0 = std::chrono::steady_clock::now();
         s = single_pass_into_context_buffer(ctx, atoms->n, d, params, ctx->prof.enabled ? &ctx->prof : nullptr, &total);
         if (timing) fprintf(stderr, "    pair pass (launches + sync)      %8.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -805,11 +802,10 @@ void run_helpers(int helpers, size_t n, F &&fn) {  // fn(item) over [0, n) on up
     if (first_error) std::rethrow_exception(first_error);
 }
 
-const bool g_batch_timing = getenv("ARP_TIMING") != nullptr;
-struct BatchLap {  // ARP_TIMING=1: where a pack's host time goes (stderr)
+struct BatchLap {  // arp_debug_set("timing", 1): where a pack's host time goes (stderr)
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void operator()(const char *what) {
-        if (!g_batch_timing) return;
+        if (!g_debug.timing) return;
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "    batch %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
         t = now;
@@ -1229,6 +1225,17 @@ extern "C" int32_t arp_profile_read(arp_context *ctx, const char **names, float 
 }
 
 // ---- library-level -----------------------------------------------------------------------------------------------
+namespace arp { DebugKnobs g_debug{0, 0, 0, 0}; }
+extern "C" arp_status arp_debug_set(const char *key, int64_t value) {
+    if (!key) { set_error("null key"); return ARP_ERR_BAD_INPUT; }
+    const std::string k(key);
+    if (k == "timing") g_debug.timing = value != 0;
+    else if (k == "emit_kernel") g_debug.emit_kernel = (int)value;
+    else if (k == "defer_entries") g_debug.defer_entries = (long)value;
+    else if (k == "table_host") g_debug.table_host = value != 0;
+    else { set_error("arp_debug_set: unknown key '%s' (timing, emit_kernel, defer_entries, table_host)", key); return ARP_ERR_BAD_INPUT; }
+    return ARP_OK;
+}
 extern "C" int32_t arp_api_version(void) { return ARP_API_VERSION; }
 extern "C" arp_status arp_check_api_version(int32_t header_version) {
     if (header_version == ARP_API_VERSION) return ARP_OK;

@@ -73,6 +73,7 @@ DEVFN float grid_setup(const double lo_in[3], const double hi_in[3], bool empty,
 // (A single launch with an arrival ticket was measured 2-3x slower: the per-block device-scope atomics / write-through
 // stores cost more than the extra launch.)  partials: [kBoundsBlocks][8] doubles = {min xyz, max xyz, models, bad}.
 constexpr uint32_t kBoundsBlocks = 256, kBoundsThreads = 1024;
+constexpr uint32_t kScanBlocks = 1024, kScanThreads = 256, kScanPartAt = 32;  // (the scan's block decomposition; its chunk totals live behind the 32 result words)
 struct BoxAcc {
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t models = 0, bad = 0;
@@ -187,6 +188,8 @@ DEVFN void setup_block(BoxAcc &acc, SetupLds &l, bool publish, GridParams *g, De
     if (publish) {
         for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
         if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results
+        // (result + 32 ..: the published chunk totals of k_scan_single, Workspace::result holds kResultWordsAll words)
+        for (uint32_t k = threadIdx.x; k < kScanBlocks; k += blockDim.x) result[kScanPartAt + k] = 0ull;
     }
     box_block_reduce<4>(acc, l.box);
     auto block_max = [&](double b) {
@@ -331,9 +334,23 @@ __global__ __launch_bounds__(kCidThreads, BOX == 0 ? 8 : 4) void k_cellid(DevAto
         }
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kCidTable; k += kCidThreads) {
-        const uint32_t key = t_key[k];
-        if (key != ARP_NONE) t_cnt[k] = atomicAdd(&cell_count[key], t_cnt[k]);  // count -> base of this block's atoms in the cell
+    {   // count -> base of this block's atoms in the cell: one returning device atomic per distinct cell of the block.  All of a thread's
+        // atomics are issued before the first answer is waited for (round 5: written as one loop, each iteration stored its answer at once and
+        // the eight round trips of a thread ran one after the other -- ~8 us of a 19 us kernel whose blocks all run at the same time)
+        constexpr uint32_t kPer = kCidTable / kCidThreads;
+        uint32_t key[kPer], base[kPer];
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint32_t k = threadIdx.x + j * kCidThreads;
+            key[j] = t_key[k];
+            base[j] = t_cnt[k];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++)
+            if (key[j] != ARP_NONE) base[j] = atomicAdd(&cell_count[key[j]], base[j]);
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++)
+            if (key[j] != ARP_NONE) t_cnt[threadIdx.x + j * kCidThreads] = base[j];
     }
     __syncthreads();
 #pragma unroll
@@ -348,8 +365,6 @@ __global__ __launch_bounds__(kCidThreads, BOX == 0 ? 8 : 4) void k_cellid(DevAto
 // decomposition so that no host knowledge of n is needed.  Three launches: per-block sums, their scan, the per-block
 // scans (a fused arrival-ticket variant was measured slower).  ZERO_IN clears the input behind itself (cell_count is
 // ready for the next call); FINISH also publishes the pair total and the status flags.
-constexpr uint32_t kScanBlocks = 1024, kScanThreads = 256;
-
 template <typename TOut>
 DEVFN TOut block_exclusive_scan(TOut v, TOut *total, TOut *lds /* [kScanThreads/64 + 1] */) {
     TOut inc = v;
@@ -425,6 +440,40 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
             if (g->bad & 1u) result[1] |= 4ull;
             if (g->bad & 2u) result[1] |= 64ull;
         }
+    }
+}
+
+// The cell scan of larger inputs in ONE launch (round 5; two before: per-block totals, then carry + apply): every block adds up its chunk and
+// publishes the total as one 64-bit word {1, total}; a block's carry is the sum of the words of the blocks before it, read with device-scope
+// loads as they appear (the words are zeroed by the grid sizing of the same call, a kernel earlier on the stream).  A block only ever waits
+// for blocks with a smaller index -- dispatched before it -- so the wait ends whatever else shares the device; value and flag travel in
+// one atomic word, so nothing else has to become visible with it.
+__global__ __launch_bounds__(kScanThreads) void k_scan_single(uint32_t *in, const uint32_t *n_ptr, unsigned long long *part, uint32_t *out) {
+    __shared__ uint32_t lds[kScanThreads / 64 + 1];
+    const uint32_t n = *n_ptr;
+    const uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
+    const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
+    uint32_t s = 0, own;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kScanThreads) s += in[i];
+    block_exclusive_scan<uint32_t>(s, &own, lds);
+    if (threadIdx.x == 0) __hip_atomic_store(&part[blockIdx.x], (1ull << 32) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t before = 0, carry;
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += kScanThreads) {
+        unsigned long long v;
+        do { v = __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) == 0ull);
+        before += (uint32_t)v;
+    }
+    __syncthreads();
+    block_exclusive_scan<uint32_t>(before, &carry, lds);
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0) out[n] = carry + own;  // (the last block's chunk ends at n: the grand total)
+    for (uint32_t base = lo; base < hi; base += kScanThreads) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t v = (i < hi) ? in[i] : 0u, tot;
+        const uint32_t ex = block_exclusive_scan<uint32_t>(v, &tot, lds);
+        if (i < hi) { out[i] = carry + ex; in[i] = 0; }  // (clears cell_count behind itself: ready for the next call)
+        carry += tot;
+        __syncthreads();
     }
 }
 

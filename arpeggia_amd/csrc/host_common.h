@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/arpeggia_amd.h"
+#include "debug_knobs.h"
 
 namespace arp {
 

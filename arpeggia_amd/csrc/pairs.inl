@@ -682,7 +682,7 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
     P1();
     P0("grid_scan");
     if (!in.per_model && n <= kScanOneAtoms) hipLaunchKernelGGL(k_scan_one<true>, dim3(1), dim3(kScanOneThreads), 0, st, ws.cell_count, (const uint32_t *)&ws.grid->ncells, ws.cell_start);
-    else launch_scan<uint32_t, true, false>(ws.cell_count, &ws.grid->ncells, ws.scan_tmp, ws.cell_start, ws.tickets + 1, ws, 0ull, false, st);
+    else hipLaunchKernelGGL(k_scan_single, dim3(kScanBlocks), dim3(kScanThreads), 0, st, ws.cell_count, (const uint32_t *)&ws.grid->ncells, ws.result + kScanPartAt, ws.cell_start);
     P1();
     P0("grid_sort");
     if (ordered) {
@@ -774,8 +774,8 @@ bool launch_emit(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsigne
         return false;
     }
     // The default is k_emit (pairs_emit.inl).  This file's k_pairs<kEmit> -- both exact operands gathered, 8-byte queue entries -- is the
-    // one alternative kept: it takes the inputs beyond k_emit's 2^24 slots, and ARP_EMIT_KERNEL=gather selects it for the parity suite.
-    static const bool gather = [] { const char *e = getenv("ARP_EMIT_KERNEL"); return e && e[0] == 'g'; }();
+    // one alternative kept: it takes the inputs beyond k_emit's 2^24 slots, and arp_debug_set("emit_kernel", 1) selects it for the parity suite.
+    const bool gather = g_debug.emit_kernel == 1;  // (arp_debug_set("emit_kernel", 1): the parity suite's run of the alternative kernel)
     if (!gather && in.n < (1u << kESlotBits) - 64u) return launch_emit_e(in, ws, out, capacity, st, prof, contacts_only, skip_deferred, res_filter && emit_takes_res_filter(in));
     EmitTarget tg{out, capacity, ws.scratch, ws.scratch_cap, ws.defer_list, ws.defer_cap};
     const uint32_t nb = blocks_for(in.n, kEmitBlocks);

@@ -637,7 +637,7 @@ extern "C" arp_status arp_structure_load(const char *path, int32_t ignore_zero_o
     arp_structure *s = new arp_structure();
     st = build(recs, 0, ignore_zero_occupancy != 0, s);
     auto T2 = std::chrono::steady_clock::now();
-    if (getenv("ARP_TIMING")) fprintf(stderr, "read %.3f ms build %.3f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count());
+    if (g_debug.timing) fprintf(stderr, "read %.3f ms build %.3f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count());
     if (st != ARP_OK) { delete s; return st; }
     *out = s;
     return ARP_OK;

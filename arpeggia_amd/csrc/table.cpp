@@ -343,7 +343,7 @@ TableCache *table_cache_of(arp_structure *s) {
     std::unique_ptr<TableCache> holder(new TableCache());  // (published at the end: an exception on the way leaks nothing, and its job is joined)
     TableCache *c = holder.get();
     const size_t n = s->n, nr = s->residues.size();
-    const bool timing = getenv("ARP_TIMING") != nullptr;
+    const bool timing = g_debug.timing != 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -520,7 +520,7 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
         uint64_t total = 0;
         for (const Seg &g : seg) total += (g.bytes + 255u) & ~255ull;
         total = std::max<uint64_t>(total, 256);
-        const bool timing = getenv("ARP_TIMING") != nullptr;
+        const bool timing = g_debug.timing != 0;
         auto t_prev = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) {
             if (!timing) return;
@@ -566,7 +566,7 @@ arp_status ensure_resident(arp_context *ctx, arp_structure *s, TableCache *c, co
 }
 
 arp_status get_contacts_device(arp_context *ctx, arp_structure *s, const char *groups, double vdw_comp, double dist_cutoff, arp_table **out) {
-    const bool timing = getenv("ARP_TIMING") != nullptr;
+    const bool timing = g_debug.timing != 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -651,7 +651,7 @@ extern "C" arp_status arp_get_contacts_mt(arp_context *ctx, arp_structure *s, co
     *out = nullptr;
     HostThreadsScope threads(num_threads);  // one worker count for every pass of this call
 #ifdef ARP_WITH_HOST_TABLE   // test-only build (tests/hosttable): the round-1 host assembly as a cross-check of the device table
-    if (getenv("ARP_TABLE_HOST") != nullptr) return get_contacts_host(ctx, s, groups, vdw_comp, dist_cutoff, out);
+    if (g_debug.table_host) return get_contacts_host(ctx, s, groups, vdw_comp, dist_cutoff, out);
 #endif
     return get_contacts_device(ctx, s, groups, vdw_comp, dist_cutoff, out);
 } ARP_ABI_CATCH

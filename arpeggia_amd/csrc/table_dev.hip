@@ -430,7 +430,7 @@ arp_status device_planes(arp_context *ctx, const DevStructure &ds, std::vector<d
 arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<RingEnt> &rings, const std::vector<EntKey> &ring_keys, const arp_pair *pairs_dev,
                         uint64_t n_pairs, double dist_cutoff, TableRowsHost *out) {
     hipStream_t st = (hipStream_t)context_stream(ctx);
-    const bool timing = getenv("ARP_TIMING") != nullptr;
+    const bool timing = g_debug.timing != 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;

@@ -99,8 +99,51 @@ def pack_soas(soas):
     return out
 
 
+_M64 = (1 << 64) - 1
+_K1, _K2, _K3 = 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0xD6E8FEB86659FD93
+
+
+def record_hash_numpy(i, j, dist_f32, kind) -> int:
+    """Order-independent 64-bit hash of a pair list: the wrapping sum over the records of a 64-bit mix of (i, j, distance bits, kind).
+    The same arithmetic as record_hash_device, on the oracle's list (numpy uint64 wraps)."""
+    import numpy as np
+
+    x = i.astype(np.uint64) | (j.astype(np.uint64) << np.uint64(32))
+    y = np.ascontiguousarray(dist_f32, dtype=np.float32).view(np.uint32).astype(np.uint64) | (kind.astype(np.uint64) << np.uint64(32))
+    with np.errstate(over="ignore"):
+        h = (x * np.uint64(_K1)) ^ (y * np.uint64(_K2))
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(_K3)
+        h ^= h >> np.uint64(32)
+        return int(h.sum(dtype=np.uint64))
+
+
+def record_hash_device(torch, out, n) -> int:
+    """record_hash_numpy on the device-resident records out[0:n] (int32 [n, 4] = i, j, distance bits, kind): int64 arithmetic wraps like
+    uint64, logical shifts are arithmetic shifts with the sign extension masked off."""
+    def s64(v):  # the int64 with the bit pattern of the uint64 v
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    total = 0
+    for lo in range(0, n, 1 << 24):  # (in slices: the temporaries of a 3 x 10^7-record list stay below 1 GB)
+        r = out[lo:min(n, lo + (1 << 24))].to(torch.int64) & 0xFFFFFFFF
+        x = r[:, 0] | (r[:, 1] << 32)
+        y = r[:, 2] | (r[:, 3] << 32)
+        h = (x * s64(_K1)) ^ (y * s64(_K2))
+        h = h ^ ((h >> 29) & ((1 << 35) - 1))
+        h = h * s64(_K3)
+        h = h ^ ((h >> 32) & 0xFFFFFFFF)
+        total = (total + int(h.sum().item())) & _M64
+    return total
+
+
+LAST: dict = {}  # what the most recent measure_resident() saw besides its return values: first_call_ms, pair_hash
+
+
 def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, profile_steps, barrier, check=True):
-    """`steps` passes over one device-resident SoA: (wall seconds over the steps, device ms per step, pairs, per-kernel ms)."""
+    """`steps` passes over one device-resident SoA: (wall seconds over the steps, device ms per step, pairs, per-kernel ms).
+    LAST receives the device time of the FIRST pass on these arrays (no memo yet: the probe pass is launched, the kernels are the
+    default ones) and, after the timed steps, the order-independent hash of the emitted records."""
     dsoa = to_device(soa, torch, dev)
     keep = []
     atoms = aa.atoms_from_arrays(dsoa, location=_lib.ARP_MEM_DEVICE, keep=keep)
@@ -109,6 +152,14 @@ def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, p
     n_pairs = ctx.count(atoms, prm)  # size the output once (count pass), then everything is allocation-free
     cap = max(n_pairs, 1) if check else n_pairs + n_pairs // 16 + 4096  # (diagnostic ablation builds, --no-check: their passes need not agree on the count)
     out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    LAST.clear()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record(stream)
+    ctx.enqueue(atoms, prm, out.data_ptr(), cap)  # the first pass on these arrays (untimed by the steps below)
+    f1.record(stream)
+    got = ctx.result()
+    LAST["first_call_ms"] = f0.elapsed_time(f1)
+    assert not check or got == n_pairs
     for _ in range(warmup):
         ctx.enqueue(atoms, prm, out.data_ptr(), cap)
     got = ctx.result() if warmup else n_pairs
@@ -125,6 +176,7 @@ def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, p
     got = ctx.result()
     assert not check or got == n_pairs
     dev_ms = ev0.elapsed_time(ev1) / steps
+    LAST["pair_hash"] = record_hash_device(torch, out, got)  # what the LAST timed step left in the buffer
     # per-kernel durations (HIP events on the same stream, separate pass so they do not perturb the timed region)
     acc: dict = {}
     if profile_steps:
@@ -183,7 +235,22 @@ def batch5k_share(aa, synth, sizes, mine, pool=48):
     return [made[min(picks, key=lambda q: (abs(int(sizes[q]) - int(sizes[k])), q))] for k in mine]
 
 
-def cpu_baseline(n_atoms: int, workload: str, seed: int = 0xBA5E, gpu_pairs=None):
+def host_cpu_share() -> tuple:
+    """(threads this process may run at once, how that is known): the cgroup's CPU quota when there is one (a GPU box leases a share of the
+    host with its GPU), else the affinity mask."""
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period) + 0.5)), f"cgroup cpu.max {quota}/{period}"
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0)), "sched_getaffinity"
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1, "os.cpu_count"
+
+
+def cpu_baseline(n_atoms: int, workload: str, seed: int = 0xBA5E, gpu_pairs=None, gpu_hash=None):
     """The oracle ("port": this repo's C restatement, NOT the reference binary) on bounded samples: one thread on the headline
     cloud, then all host threads at once, each on its own independent 10^5-atom cloud (the reference's -j 0, utils.rs:8-30)."""
     import threading
@@ -197,7 +264,8 @@ def cpu_baseline(n_atoms: int, workload: str, seed: int = 0xBA5E, gpu_pairs=None
     t0 = time.perf_counter()
     pairs = s.atomic_contacts("/", 0.1, 6.5)
     dt = time.perf_counter() - t0
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    share, share_src = host_cpu_share()
+    threads = max(1, min(share, os.cpu_count() or 1, 256))  # every host thread this process may use (round 4 capped this at 64 whatever the box)
     small = ob.Structure.from_atoms(synth.records_to_oracle(gen(100_000, seed=0xBA5E + 1), flat=True), flat=True)
     counts = [0] * threads
 
@@ -222,10 +290,16 @@ def cpu_baseline(n_atoms: int, workload: str, seed: int = 0xBA5E, gpu_pairs=None
         "sample": f"{workload.upper()} synthetic cloud, {n_atoms} atoms -> {len(pairs)} pairs, grid search + per-pair rules, "
                   f"{dt:.1f} s on 1 of {os.cpu_count()} host threads",
         "all_cores": {"value": sum(counts) / dt_all, "cores": threads,
-                      "sample": f"{threads} of {os.cpu_count()} host threads, each one independent 100000-atom cloud ({counts[0]} pairs), {dt_all:.1f} s"},
+                      "sample": f"{threads} threads = this process's share of the host's {os.cpu_count()} ({share_src}), each one independent 100000-atom cloud "
+                                f"({counts[0]} pairs), {dt_all:.1f} s"},
         "reference_toolchain": cargo or "cargo not found on this box: the reference (Rust) cannot be built or timed here",
         "note": "restatement CPU baseline (oracle/arp_oracle.c), not the reference binary",
         **({"same_cloud_as_gpu": True, "pair_count_equals_gpu": bool(len(pairs) == gpu_pairs)} if gpu_pairs is not None else {}),
+        # the records themselves: order-independent 64-bit hash over (i, j, f32 distance bits, kind) of the oracle's list against the same hash of
+        # what the last timed GPU step left in the output buffer (the timed call path itself, content-checked at the headline size)
+        **({"pair_set_hash": f"{record_hash_numpy(pairs['i'], pairs['j'], pairs['dist'].astype('float32'), pairs['kind']):016x}", "pair_set_hash_gpu": f"{gpu_hash:016x}",
+            "pair_set_hash_equals_gpu": bool(record_hash_numpy(pairs['i'], pairs['j'], pairs['dist'].astype('float32'), pairs['kind']) == gpu_hash)}
+           if gpu_hash is not None and gpu_pairs is not None else {}),
     }
 
 
@@ -306,6 +380,7 @@ def main():
         for p in packs:  # (one pack unless a rank holds more than 60000 structures)
             w, d, npair, a, na = measure_resident(aa, _lib, torch, dev, dev_index, p, prm, args.steps, args.warmup, args.profile_steps, barrier, check)
             wall += w; dev_ms += d; n_pairs += npair; n_atoms += na
+            head = dict(LAST)
             for k, v in a.items():
                 acc[k] = acc.get(k, 0.0) + v
         label = (f"batch of {total} S1 structures of ~5k atoms (N(5000, 500^2) clipped to [3000, 7000]), {n_mine} on this rank as one resident multi-model pack; "
@@ -315,6 +390,7 @@ def main():
         wall, dev_ms, n_pairs, acc, n_atoms = measure_resident(aa, _lib, torch, dev, dev_index, cloud(args.workload), prm, args.steps, args.warmup,
                                                                 args.profile_steps, barrier, check)
         label = f"{args.workload.upper()} synthetic {n_atoms}-atom cloud per GPU (tests/synth.py gen_{args.workload})"
+        head = dict(LAST)
         scaling = "weak"
         if not args.no_extras and not args.deterministic and not args.contacts_only:
             other = "s1" if args.workload == "s2" else "s2"
@@ -437,7 +513,12 @@ def main():
                 "workload": f"{label}, groups='/', vdw_comp=0.1, dist_cutoff=6.5",
                 "atoms_per_gpu": n_atoms, "pairs_per_gpu": n_pairs, "pairs_all_gpus": pairs_all, "sharding": "independent structures per rank, no collective",
                 "emitter": ("ordered two-pass" if args.deterministic else "single-pass") + (", contacts only (kind != 0)" if args.contacts_only else ""),
+                # what the timed steps (2..N on the same arrays) do not pay and a first call does: see first_call_ms
+                "speculation": "none (ordered emitter)" if args.deterministic else
+                               "steps 2..N on the same device arrays skip the launch of the EMPTY probe pass (memo of the previous call, validated on the device by k_fixup); "
+                               "the emit kernels are picked from a sample of the previous call's atoms (residue-rule kernels for inputs whose residues are runs of atoms)",
             },
+            "first_call_ms": head.get("first_call_ms"),  # device time of the first pass on these arrays: probe pass launched, default kernels
             "roofline": roofline_of(n_atoms, n_pairs, acc, dev_ms, traffic),
             "device_ms_per_step": dev_ms,
         }
@@ -451,7 +532,7 @@ def main():
             wl = args.workload if args.workload in ("s1", "s2") else "s2"
             same = args.cpu_sample_atoms == args.atoms and args.workload in ("s1", "s2") and not os.environ.get("ARP_BENCH_ORDER")
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_atoms, wl, SEED + (4 if wl == "s2" else 3) if same else 0xBA5E,
-                                                n_pairs if same and not args.contacts_only else None)
+                                                n_pairs if same and not args.contacts_only else None, head.get("pair_hash") if same and not args.contacts_only else None)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

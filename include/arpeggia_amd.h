@@ -141,6 +141,15 @@ typedef struct arp_structure arp_structure; /* parsed + filtered model (utils.rs
 typedef struct arp_table arp_table;         /* the 20-column contact table (mod.rs:140-214)          */
 
 /* ---- library / device ---- */
+/* Diagnostics -- not part of the reference's surface.  The library reads ONE environment variable, ARPEGGIA_AMD_HOST_POOL_MB (idle pinned host
+ * memory kept for the next batch / table, default 4096); every other switch is set here, process-wide:
+ *   "timing"        1: stage laps of the table, batch and ingest paths on stderr
+ *   "emit_kernel"   1: the single-pass emitter runs its alternative kernel (both operands gathered; the route of inputs beyond 2^24 slots), so that
+ *                      the parity suite can check it on ordinary inputs; 0 (default): chosen by input size
+ *   "defer_entries" N > 0: entries of the deferred-probe list of workspaces allocated from now on (a tiny list makes the grow-and-repeat path run)
+ *   "table_host"    1: only in the test library built with -DARP_WITH_HOST_TABLE (tests/hosttable): arp_get_contacts assembles the table on the host
+ * Unknown keys return ARP_ERR_BAD_INPUT. */
+arp_status arp_debug_set(const char *key, int64_t value);
 int32_t arp_api_version(void);
 /* A binder compiled against this header calls arp_check_api_version(ARP_API_VERSION) once: ARP_OK when the library lays out arp_atoms /
  * arp_params / arp_pair as that version of the header does, ARP_ERR_BAD_INPUT (+ arp_last_error) otherwise -- a v1 caller (16-bit chain

@@ -2,6 +2,7 @@
 out: PCIe inclusive), against one call per structure; full candidate lists and ARP_FLAG_CONTACTS_ONLY.
 Usage (GPU box): python tests/batch_timing.py [n_structures]"""
 import ctypes as C
+import os
 import sys
 import time
 
@@ -10,6 +11,9 @@ import numpy as np
 _here = __import__("pathlib").Path(__file__).resolve().parent
 sys.path[:0] = [str(_here), str(_here.parent)]
 import arpeggia_amd as aa  # noqa: E402
+
+if os.environ.get("ARP_TIMING"):  # (a switch of THIS script: the library reads no environment)
+    aa.debug_set("timing", 1)
 import synth  # noqa: E402
 from arpeggia_amd import _lib  # noqa: E402
 

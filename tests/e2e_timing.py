@@ -1,5 +1,6 @@
 """End-to-end cost of the file-level drop-in `contacts(path)` on the two reference structures: parse + SoA, GPU pairs,
 host table, Arrow hand-over.  Usage (GPU box): python tests/e2e_timing.py > profiles/rNN_e2e.txt"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -7,6 +8,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 import arpeggia_amd as aa  # noqa: E402
+
+if os.environ.get("ARP_TIMING"):  # (a switch of THIS script: the library reads no environment)
+    aa.debug_set("timing", 1)
 
 
 def best(fn, n=7):

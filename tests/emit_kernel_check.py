@@ -1,5 +1,5 @@
-"""Parity of ONE emit kernel variant against the oracle, in a process of its own (ARP_EMIT_KERNEL is read once per process).
-Run by tests/test_gpu_parity.py::test_alternative_emit_kernels; usage: ARP_EMIT_KERNEL=gather python tests/emit_kernel_check.py"""
+"""Parity of ONE emit kernel variant against the oracle, in a process of its own (arp_debug_set("emit_kernel", ...) is process-wide).
+Run by tests/test_gpu_parity.py::test_alternative_emit_kernels; usage: python tests/emit_kernel_check.py gather"""
 import sys
 from pathlib import Path
 
@@ -27,6 +27,7 @@ def check(ctx, prod, orc, what, **kw):
 
 
 def main():
+    aa.debug_set("emit_kernel", {"default": 0, "gather": 1}[sys.argv[1] if len(sys.argv) > 1 else "gather"])
     ctx = aa.Context(0)
     for name in ("1ubq", "6bft"):
         path = str(synth.DATA / f"{name}.pdb")

@@ -1,6 +1,6 @@
 """Contact tables from the HOST assembly (tests/hosttable/table_host.inl), which only the test-only library contains.  Run by
 tests/test_gpu_parity.py::test_device_table_equals_the_host_assembly in a process of its own:
-    ARPEGGIA_AMD_LIB=tests/hosttable/build/libarpeggia_amd_hosttable.so ARP_TABLE_HOST=1 python tests/hosttable/dump_table.py
+    ARPEGGIA_AMD_LIB=tests/hosttable/build/libarpeggia_amd_hosttable.so python tests/hosttable/dump_table.py
 Prints one JSON object {case: {groups: [csv lines]}}."""
 import json
 import os
@@ -9,8 +9,10 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
-assert os.environ.get("ARP_TABLE_HOST") == "1" and "hosttable" in os.environ.get("ARPEGGIA_AMD_LIB", "")
+assert "hosttable" in os.environ.get("ARPEGGIA_AMD_LIB", "")
 import arpeggia_amd as aa  # noqa: E402
+
+aa.debug_set("table_host", 1)  # (only this test-only library contains the host assembly)
 import synth  # noqa: E402
 from test_gpu_parity import _table_lines, table_cases  # noqa: E402
 

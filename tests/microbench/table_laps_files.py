@@ -1,7 +1,7 @@
 import os, sys
-os.environ["ARP_TIMING"]="1"
 sys.path[:0]=["/root/repo","/root/repo/tests"]
 import arpeggia_amd as aa
+aa.debug_set("timing", 1)
 ctx = aa.Context(0)
 for name in ("1ubq","6bft"):
     s = aa.load_model(f"/root/repo/tests/data/{name}.pdb")

@@ -1,6 +1,6 @@
 """Where the table path spends its time on a large structure (S1: ubiquitin copies on a lattice).  ARP_TIMING=1 prints the stages.
 Usage (GPU box): ARP_TIMING=1 python tests/table_scaling.py [n_atoms]
-The host-assembly rows (ARP_TABLE_HOST) only mean something with the TEST-ONLY library, which is the one that contains that code:
+The host-assembly rows (arp_debug_set("table_host", 1)) only mean something with the TEST-ONLY library, which is the one that contains that code:
 ARPEGGIA_AMD_LIB=tests/hosttable/build/libarpeggia_amd_hosttable.so (arpeggia_amd/build.py build_host_table_library)."""
 import ctypes as C
 import os
@@ -11,6 +11,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 import arpeggia_amd as aa  # noqa: E402
+
+if os.environ.get("ARP_TIMING"):  # (a switch of THIS script: the library reads no environment)
+    aa.debug_set("timing", 1)
 import synth  # noqa: E402
 from arpeggia_amd import _lib  # noqa: E402
 
@@ -23,10 +26,7 @@ lib = _lib.lib
 
 def c_call(threads, host):
     """arp_get_contacts_mt alone, then the Arrow export: (seconds, seconds, rows)."""
-    if host:
-        os.environ["ARP_TABLE_HOST"] = "1"
-    else:
-        os.environ.pop("ARP_TABLE_HOST", None)
+    aa.debug_set("table_host", 1 if host else 0)
     t = C.c_void_p()
     t0 = time.perf_counter()
     st = lib.arp_get_contacts_mt(ctx._h, s._h, b"/", 0.1, 6.5, threads, C.byref(t))
@@ -57,7 +57,7 @@ for host in ((False, True) if has_host_assembly and not os.environ.get("ARP_DEVI
         best = min((c_call(threads, host) for _ in range(3)), key=lambda r: r[0] + r[1])
         print(f"S1 {s.n_atoms} atoms, {'host assembly (round 1)' if host else 'device table'}, {threads:2d} host thread(s): "
               f"get_contacts {best[0] * 1e3:7.1f} ms + Arrow export {best[1] * 1e3:6.1f} ms, {best[2]} rows", file=sys.stderr)
-os.environ.pop("ARP_TABLE_HOST", None)
+aa.debug_set("table_host", 0)
 for threads in (1, 16):
     cols = ctx.get_contacts(s)
     key = tuple(cols[c].tobytes() for c in ("model", "interaction", "distance", "from_atom", "to_atom", "sc_dihedral"))

@@ -630,6 +630,7 @@ def test_packed_batch_with_model_ordinals_beyond_the_pack_tables(ctx):
     recs = [synth.gen_s1(1200 + 300 * k, seed=400 + k) for k in range(4)]
     soas = [aa.Structure.from_records(r, hierarchy=True).soa("/") for r in recs]
     singles = [ctx.atomic_contacts(s, aa.default_params(contacts_only=True)) for s in soas]
+    ctx = aa.Context(0)  # a fresh, small workspace: whether a sparse ordinal is an error depends on the cells the workspace holds (70 001 slabs fit a large one)
     for sparse in (70000, 0xFFFFFFFF):
         bad = dict(soas[1]); bad["model"] = soas[1]["model"].copy(); bad["model"][len(bad["model"]) // 2:] = sparse
         with pytest.raises(aa.ArpeggiaError) as e:
@@ -651,13 +652,11 @@ def test_packed_batch_with_model_ordinals_beyond_the_pack_tables(ctx):
 
 @pytest.mark.parametrize("kernel", ["gather"])
 def test_alternative_emit_kernels(kernel):
-    """The one alternative single-pass emit kernel (k_pairs<kEmit>: the route of inputs beyond 2^26 slots; ARP_EMIT_KERNEL=gather, read once per
-    process) stays parity-green, in a process of its own."""
-    import os
+    """The one alternative single-pass emit kernel (k_pairs<kEmit>: the route of inputs beyond 2^24 slots; arp_debug_set("emit_kernel", 1), a
+    process-wide switch) stays parity-green, in a process of its own."""
     import subprocess
     import sys
-    env = dict(os.environ, ARP_EMIT_KERNEL=kernel)
-    r = subprocess.run([sys.executable, str(synth.DATA.parent / "emit_kernel_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, str(synth.DATA.parent / "emit_kernel_check.py"), kernel], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -695,6 +694,22 @@ def test_config5_batch_every_member_matches_the_oracle(ctx):
     for k in (0, 17, 71):
         for det in (False, True):
             assert_pairs_equal(ctx.atomic_contacts(views[k], aa.default_params(deterministic=det)), wants[k], f"single call member {k}")
+
+
+def test_lds_reads_past_the_allocation_return_zero():
+    """The hardware contract behind k_emit's prefilter runs: a lane past its window end keeps reading 16-byte records at
+    immediate offsets -- at worst beyond the block's LDS allocation -- and only its result bits are dropped.  gfx9 bounds-checks LDS addresses
+    against the workgroup's allocation: such a read returns 0 and raises nothing.  tests/lds_oob/lds_oob.hip reads from just past a 4 KB
+    allocation up to 2 GB beyond it and checks every word (in range: the fill pattern; out of range: 0)."""
+    import subprocess
+
+    src = synth.DATA.parent / "lds_oob" / "lds_oob.hip"
+    so = src.with_name("liblds_oob.so")
+    if not so.exists():
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    lib = C.CDLL(str(so))
+    lib.lds_oob_check.restype = C.c_int
+    assert lib.lds_oob_check(1) == 0
 
 
 # ---------------------------------------------------------------------------------------------- robustness (round-1 review)
@@ -851,16 +866,20 @@ def test_no_speculation_flag_makes_the_enqueued_list_final_on_the_stream(n_res):
             assert_pairs_equal(early, want_b, "device-side copy taken between enqueue and result, small input, no flag")
 
 
-def test_deferred_list_overflow_grows_and_repeats(monkeypatch):
+def test_deferred_list_overflow_grows_and_repeats():
     # hydrogen-rich structure: thousands of candidates need a probe; a 65536-entry list (every block holds a partly used 512-entry chunk) overflows and is grown 4x per retry
     rec = synth.gen_stress(n_res=600, seed=91)
     prod = aa.Structure.from_records(rec)
     want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False).atomic_contacts()
-    monkeypatch.setenv("ARP_DEBUG_DEFER_ENTRIES", "65536")
-    c = aa.Context(0)
-    for det in (False, True):
-        assert_pairs_equal(c.atomic_contacts(prod.view("/"), aa.default_params(deterministic=det)), want, f"grown list det={det}")
-    monkeypatch.delenv("ARP_DEBUG_DEFER_ENTRIES")
+    aa.debug_set("defer_entries", 65536)  # (the workspaces allocated from now on: the fresh context below)
+    try:
+        c = aa.Context(0)
+        for det in (False, True):
+            assert_pairs_equal(c.atomic_contacts(prod.view("/"), aa.default_params(deterministic=det)), want, f"grown list det={det}")
+    finally:
+        aa.debug_set("defer_entries", 0)
+    with pytest.raises(aa.ArpeggiaError):
+        aa.debug_set("no_such_switch", 1)
 
 
 # ---------------------------------------------------------------------------------------------- SAP neighbour sum
@@ -993,7 +1012,7 @@ def test_device_table_equals_the_host_assembly(ctx):
     from arpeggia_amd import build as B
 
     lib = B.build_host_table_library()
-    env = dict(os.environ, ARPEGGIA_AMD_LIB=str(lib), ARP_TABLE_HOST="1")
+    env = dict(os.environ, ARPEGGIA_AMD_LIB=str(lib))  # (the child switches the host assembly on: arp_debug_set("table_host", 1))
     r = subprocess.run([sys.executable, str(synth.DATA.parent / "hosttable" / "dump_table.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     host = json.loads(r.stdout.strip().splitlines()[-1])
