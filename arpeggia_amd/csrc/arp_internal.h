@@ -163,6 +163,6 @@ bool emit_takes_res_filter(const DevAtoms &in);  // the single-pass emitter has 
 unsigned long long emit_scratch_records();
 void launch_neighbor_sum(const DevAtoms &in, const Workspace &ws, double radius, double r2, const float *weight, float *out, hipStream_t st, Profiler *prof);
 void launch_pack_fix(const PackArrays &pa, hipStream_t st);
-void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, bool ordered, hipStream_t st);
+void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, unsigned long long capacity, arp_pair *grouped, bool ordered, hipStream_t st);
 
 }  // namespace arp

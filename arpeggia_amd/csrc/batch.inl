@@ -104,8 +104,13 @@ DEVFN void split_range(unsigned long long P, unsigned long long *lo, unsigned lo
     *lo = min(P, w * per); *hi = min(P, *lo + per);
 }
 
-__global__ __launch_bounds__(kSplitThreads) void k_split_count(const unsigned long long *result, const arp_pair *pairs, uint32_t K, const PackDesc *desc, unsigned long long *count) {
-    const unsigned long long P = result[0];
+// (capacity: the records `pairs` holds.  A pack whose list did not fit -- result[0] > capacity: the fix-up then only reports the size, and the host grows
+// the buffer and runs the pack again -- is not split at all: round 5 found the split kernels reading result[0] records out of a buffer that held
+// fewer, a fault as soon as the excess left the allocation's padding.)
+DEVFN unsigned long long split_records(const unsigned long long *result, unsigned long long capacity) { return result[0] <= capacity ? result[0] : 0ull; }
+__global__ __launch_bounds__(kSplitThreads) void k_split_count(const unsigned long long *result, unsigned long long capacity, const arp_pair *pairs, uint32_t K, const PackDesc *desc,
+                                                               unsigned long long *count) {
+    const unsigned long long P = split_records(result, capacity);
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long lo, hi;
     split_range(P, &lo, &hi);
@@ -150,11 +155,11 @@ __global__ __launch_bounds__(1024) void k_split_scan(uint32_t K, const unsigned 
 // member's places with ONE atomic, then copies; if its range mentions more members than the table holds (packs of tiny structures), the
 // rest of the range reserves per 64 records.
 struct SplitTable { uint32_t member[kSplitSlots], count[kSplitSlots], run[kSplitSlots]; unsigned long long base[kSplitSlots]; };
-__global__ __launch_bounds__(kSplitThreads) void k_split_scatter(const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, uint32_t K, const PackDesc *desc,
-                                                                unsigned long long *cursor) {
+__global__ __launch_bounds__(kSplitThreads) void k_split_scatter(const unsigned long long *result, unsigned long long capacity, const arp_pair *pairs, arp_pair *grouped, uint32_t K,
+                                                                const PackDesc *desc, unsigned long long *cursor) {
     __shared__ SplitTable tables[kSplitThreads / 64];
     SplitTable &t = tables[threadIdx.x >> 6];  // (private to the wave: its lanes run in lockstep, LDS operations of one wave stay in order)
-    const unsigned long long P = result[0];
+    const unsigned long long P = split_records(result, capacity);
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long lo, hi;
     split_range(P, &lo, &hi);
@@ -226,10 +231,10 @@ void launch_pack_fix(const PackArrays &pa, hipStream_t st) {
     hipLaunchKernelGGL(k_pack_fix, dim3(nb ? nb : 1u), dim3(256), 0, st, pa.n, pa.n_res, pa.n_h, pa.K, (const PackDesc *)pa.desc, (const uint32_t *)pa.status, pa.model, pa.res_id,
                        pa.res_h_ptr, pa.res_cb, pa.res_sg, pa.res_h_idx);
 }
-void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, arp_pair *grouped, bool ordered, hipStream_t st) {
+void launch_pack_split(const PackArrays &pa, const unsigned long long *result, const arp_pair *pairs, unsigned long long capacity, arp_pair *grouped, bool ordered, hipStream_t st) {
     (void)hipMemsetAsync(pa.count, 0, sizeof(unsigned long long) * pa.K, st);
-    hipLaunchKernelGGL(k_split_count, dim3(kSplitBlocks), dim3(kSplitThreads), 0, st, result, pairs, pa.K, (const PackDesc *)pa.desc, pa.count);
+    hipLaunchKernelGGL(k_split_count, dim3(kSplitBlocks), dim3(kSplitThreads), 0, st, result, capacity, pairs, pa.K, (const PackDesc *)pa.desc, pa.count);
     hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, st, pa.K, (const unsigned long long *)pa.count, pa.offset, pa.cursor);
     (void)ordered;
-    hipLaunchKernelGGL(k_split_scatter, dim3(kSplitBlocks), dim3(kSplitThreads), 0, st, result, pairs, grouped, pa.K, (const PackDesc *)pa.desc, pa.cursor);
+    hipLaunchKernelGGL(k_split_scatter, dim3(kSplitBlocks), dim3(kSplitThreads), 0, st, result, capacity, pairs, grouped, pa.K, (const PackDesc *)pa.desc, pa.cursor);
 }

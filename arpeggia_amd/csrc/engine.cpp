@@ -866,7 +866,7 @@ arp_status enqueue_pack_kernels(BatchSlot &sl, const arp_params *params) {
     } else {
         launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only, false, ctx->rkey_valid);
     }
-    launch_pack_split(sl.pa, ctx->ws.result, ctx->out_buf, ctx->grp_buf, sl.ordered, ctx->stream);
+    launch_pack_split(sl.pa, ctx->ws.result, ctx->out_buf, std::min(ctx->out_cap, ctx->grp_cap), ctx->grp_buf, sl.ordered, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ctx->h_result, ctx->ws.result, kResultWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_offsets, sl.pa.offset, (sl.pa.K + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
