@@ -73,22 +73,36 @@ DEVFN float grid_setup(const double lo_in[3], const double hi_in[3], bool empty,
 // (A single launch with an arrival ticket was measured 2-3x slower: the per-block device-scope atomics / write-through
 // stores cost more than the extra launch.)  partials: [kBoundsBlocks][8] doubles = {min xyz, max xyz, models, bad}.
 constexpr uint32_t kBoundsBlocks = 256, kBoundsThreads = 1024;
-constexpr uint32_t kScanBlocks = 1024, kScanThreads = 256, kScanPartAt = 32;  // (the scan's block decomposition; its chunk totals live behind the 32 result words)
+constexpr uint32_t kScanBlocks = 1024, kScanThreads = 256, kScanPartAt = 32;  // (the two-launch scan's block decomposition; k_scan_single's chunk totals live behind the 32 result words)
+constexpr uint32_t kScanSingleBlocks = kScanThreads;  // one published word per thread of a later block: a single round of device-scope loads
 struct BoxAcc {
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t models = 0, bad = 0;
 };
 struct BoxLds { double mn[kBoundsThreads / 64][3], mx[kBoundsThreads / 64][3]; uint32_t models[kBoundsThreads / 64], bad[kBoundsThreads / 64]; };
+// Order-preserving codes of f32 values (unsigned compare = float compare): the box only has to CONTAIN the atoms -- cell indices are clamped, and
+// two atoms within the cutoff stay in adjacent cells under any monotone clamp -- so it is reduced as f32 values rounded outwards.
+DEVFN uint32_t f32_code(float f) { const uint32_t u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
+DEVFN float f32_decode(uint32_t c) { return __uint_as_float((c >> 31) ? (c & 0x7FFFFFFFu) : ~c); }
+DEVFN uint32_t wave_or_u32(uint32_t v) {  // (wave_reduce_u32 with |)
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 template <uint32_t NW>
 DEVFN void box_block_reduce(BoxAcc &a, BoxLds &l) {
-    for (int off = 32; off; off >>= 1) {
-        for (int k = 0; k < 3; k++) {
-            a.mn[k] = fmin(a.mn[k], __shfl_xor(a.mn[k], off));
-            a.mx[k] = fmax(a.mx[k], __shfl_xor(a.mx[k], off));
-        }
-        a.models = max(a.models, (uint32_t)__shfl_xor((int)a.models, off));
-        a.bad |= (uint32_t)__shfl_xor((int)a.bad, off);
+    // Inside a wave on the vector ALU's data-parallel primitives, as f32 codes (round 5: the f64 butterfly was 26 ds_bpermute round trips per
+    // stage, 156 per reduction, each waited for -- most of the grid sizing's time inside k_cellid and a third of k_bounds')
+    for (int k = 0; k < 3; k++) {
+        a.mn[k] = (double)f32_decode(wave_min_u32(f32_code(__double2float_rd(a.mn[k]))));
+        a.mx[k] = (double)f32_decode(wave_max_u32(f32_code(__double2float_ru(a.mx[k]))));
     }
+    a.models = wave_max_u32(a.models);
+    a.bad = wave_or_u32(a.bad);
     const uint32_t w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
@@ -151,8 +165,6 @@ __global__ __launch_bounds__(kBoundsThreads) void k_bounds(DevAtoms in, double *
 
 // Packed batches: bounding box PER MODEL, as order-preserving codes of f32 values rounded outwards (the box only has to contain
 // the atoms).  The members of a pack are contiguous, so a wave is almost always inside one model: six wave reductions, six atomics.
-DEVFN uint32_t f32_code(float f) { const uint32_t u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
-DEVFN float f32_decode(uint32_t c) { return __uint_as_float((c >> 31) ? (c & 0x7FFFFFFFu) : ~c); }
 constexpr uint32_t kPackModels = 65536;  // entries of Workspace::model_box / model_org: every index into them is clamped to this
 __global__ __launch_bounds__(256) void k_model_box_init(uint32_t *box) {  // {min xyz = +inf code, max xyz = -inf code} per model
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,11 +201,13 @@ DEVFN void setup_block(BoxAcc &acc, SetupLds &l, bool publish, GridParams *g, De
         for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
         if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results
         // (result + 32 ..: the published chunk totals of k_scan_single, Workspace::result holds kResultWordsAll words)
-        for (uint32_t k = threadIdx.x; k < kScanBlocks; k += blockDim.x) result[kScanPartAt + k] = 0ull;
+        for (uint32_t k = threadIdx.x; k < kScanSingleBlocks; k += blockDim.x) result[kScanPartAt + k] = 0ull;
     }
     box_block_reduce<4>(acc, l.box);
-    auto block_max = [&](double b) {
-        for (int off = 32; off; off >>= 1) b = fmax(b, __shfl_xor(b, off));
+    auto block_max = [&](double b) {  // (of non-negative values: the bit patterns of non-negative doubles order like unsigned integers, high word first)
+        const uint32_t hi = wave_max_u32((uint32_t)__double2hiint(b));
+        const uint32_t lo = wave_max_u32((uint32_t)__double2hiint(b) == hi ? (uint32_t)__double2loint(b) : 0u);
+        b = __hiloint2double((int)hi, (int)lo);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) l.red[threadIdx.x >> 6] = b;
         __syncthreads();
@@ -451,17 +465,17 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
 __global__ __launch_bounds__(kScanThreads) void k_scan_single(uint32_t *in, const uint32_t *n_ptr, unsigned long long *part, uint32_t *out) {
     __shared__ uint32_t lds[kScanThreads / 64 + 1];
     const uint32_t n = *n_ptr;
-    const uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
+    const uint32_t chunk = (n + kScanSingleBlocks - 1) / kScanSingleBlocks;
     const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
     uint32_t s = 0, own;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kScanThreads) s += in[i];
     block_exclusive_scan<uint32_t>(s, &own, lds);
     if (threadIdx.x == 0) __hip_atomic_store(&part[blockIdx.x], (1ull << 32) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t before = 0, carry;
-    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += kScanThreads) {
+    if (threadIdx.x < blockIdx.x) {  // thread k waits for block k's word (blocks with a smaller index were dispatched earlier)
         unsigned long long v;
-        do { v = __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) == 0ull);
-        before += (uint32_t)v;
+        do { v = __hip_atomic_load(&part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) == 0ull);
+        before = (uint32_t)v;
     }
     __syncthreads();
     block_exclusive_scan<uint32_t>(before, &carry, lds);
