@@ -666,8 +666,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
                 while (more) {
                     // Phase 1, one run: up to kEAcc prefilter tests per lane in groups of kEGroup, results pushed into the lane's mask word.
                     // Every lane reads from its own window start onwards, ALL addresses of the run being immediate offsets from one base: a
-                    // lane whose window is exhausted reads on past it (other records, the wave's other arrays, at worst beyond the block's LDS,
-                    // which reads as zero) and its bits are dropped below -- no per-group clamp, select or address arithmetic.
+                    // lane whose window is exhausted reads on past it (other records, the wave's other arrays, at worst beyond the block's LDS
+                    // allocation) and its bits are dropped below -- no per-group clamp, select or address arithmetic.  The hardware contract
+                    // this leans on is that an LDS read past the allocation never faults; the VALUE is unspecified (stale words of the
+                    // allocation granule's padding just past the end, 0 further out: tests/lds_oob, a -m gpu test) and never used.
                     const uint32_t acc0 = it0;
                     uint32_t mask = 0, nacc = 0;
                     const float4 *win = w.nrec + (off + it0);

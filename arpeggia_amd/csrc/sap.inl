@@ -90,7 +90,8 @@ __global__ __launch_bounds__(SPLIT * 64) void k_neighbor_sum(const GridParams *g
             for (uint32_t it0 = 0; __any(it0 < len); it0 += kSapGroup) {
                 float d2[kSapGroup], wt[kSapGroup];
 #pragma unroll
-                for (uint32_t u = 0; u < kSapGroup; u++) {  // (a lane past its window end reads on: other records, dropped below)
+                for (uint32_t u = 0; u < kSapGroup; u++) {  // (a lane past its window end reads on -- other records, another wave's buffer, at worst past the block's
+                                                            // LDS allocation, which never faults (tests/lds_oob) -- and the value is dropped below: `mine`)
                     const float4 r = win[it0 + u];
                     const float dx = r.x - hx, dy = r.y - hy, dz = r.z - hz;
                     d2[u] = __fmaf_rn(dx, dx, __fmaf_rn(dy, dy, dz * dz));

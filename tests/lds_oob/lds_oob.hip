@@ -1,9 +1,12 @@
-// Test-only (not part of the product): the hardware contract k_emit's prefilter leans on.  A lane whose slot window is exhausted keeps reading
-// 16-byte records at immediate offsets from its window start, its bits are dropped afterwards (pairs_emit.inl, "Phase 1, one run") -- the reads may
-// run past the wave's arrays and, for the last wave of a block, past the block's LDS allocation.  gfx9 LDS instructions bounds-check every
-// address against the workgroup's allocation: an out-of-range read returns 0 and raises nothing.  This kernel reads past a small allocation
-// on purpose (inline assembly: a C++ out-of-bounds access would be undefined behaviour for the compiler to exploit); the host checks that
-// the in-range control reads saw the pattern, that every out-of-range word came back 0, and that the launch completed without a fault.
+// Test-only (not part of the product): the hardware contract k_emit's prefilter and the SAP sum lean on.  A lane whose slot window is exhausted
+// keeps reading 16-byte records at immediate offsets from its window start and its result bits are dropped afterwards (pairs_emit.inl, "Phase 1,
+// one run"; sap.inl) -- the reads may run past the wave's arrays and, for the last wave of a block, past the block's LDS allocation.  What the
+// kernels need is that such a read NEVER FAULTS; the value is discarded.  Measured here (round 5; the first version of this test expected zeros
+// everywhere and failed): an LDS read past the workgroup's allocation raises nothing; just past the end it returns whatever the padding of the
+// allocation granule holds (stale words of earlier kernels -- so nothing may ever depend on the value), far past it returns 0.  This kernel reads
+// past a 4 KB allocation on purpose (inline assembly: a C++ out-of-bounds access would be undefined behaviour for the compiler to exploit); the
+// host checks that the in-range control reads saw the fill pattern, that reads 64 KB and more past the end came back 0, and that the launch
+// completed without a fault; it reports where the nonzero words stop.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -42,14 +45,18 @@ extern "C" int lds_oob_check(int verbose) {
     if (hipMemcpy(h.data(), d_out, n_out * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     (void)hipFree(d_off); (void)hipFree(d_out);
     int bad = 0;
+    uint64_t last_nonzero = 0;  // largest out-of-range byte offset that read back nonzero (the extent of the allocation granule's padding)
     for (uint32_t b = 0; b < blocks; b++)
         for (uint32_t j = 0; j < n_off; j++)
             for (uint32_t t = 0; t < threads; t++)
                 for (uint32_t w = 0; w < 4; w++) {
                     const uint32_t got = h[(((size_t)b * n_off + j) * threads + t) * 4 + w];
                     const uint64_t byte = (uint64_t)offsets[j] + 16u * t + 4u * w;  // offset of this word from the start of the allocation
-                    const uint32_t want = byte < 4u * kWords ? 0xA5A5A5A5u : 0u;
-                    if (got != want) { if (verbose && bad < 8) fprintf(stderr, "block %u offset %u lane %u word %u: %08x, expected %08x\n", b, offsets[j], t, w, got, want); bad++; }
+                    const bool in_range = byte < 4u * kWords, far = byte >= 4u * kWords + 65536u;
+                    if (!in_range && got != 0u && byte > last_nonzero) last_nonzero = byte;
+                    const bool ok = in_range ? got == 0xA5A5A5A5u : (far ? got == 0u : true);  // (just past the end: unspecified, only "no fault")
+                    if (!ok) { if (verbose && bad < 8) fprintf(stderr, "block %u offset %u lane %u word %u: %08x\n", b, offsets[j], t, w, got); bad++; }
                 }
+    if (verbose) fprintf(stderr, "lds_oob: allocation 4096 B; nonzero words read up to byte offset %llu past the start\n", (unsigned long long)last_nonzero);
     return bad;
 }

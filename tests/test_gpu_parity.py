@@ -697,10 +697,11 @@ def test_config5_batch_every_member_matches_the_oracle(ctx):
 
 
 def test_lds_reads_past_the_allocation_return_zero():
-    """The hardware contract behind k_emit's prefilter runs: a lane past its window end keeps reading 16-byte records at
-    immediate offsets -- at worst beyond the block's LDS allocation -- and only its result bits are dropped.  gfx9 bounds-checks LDS addresses
-    against the workgroup's allocation: such a read returns 0 and raises nothing.  tests/lds_oob/lds_oob.hip reads from just past a 4 KB
-    allocation up to 2 GB beyond it and checks every word (in range: the fill pattern; out of range: 0)."""
+    """The hardware contract behind k_emit's prefilter runs and the SAP sum: a lane past its window end keeps reading 16-byte
+    records at immediate offsets -- at worst beyond the block's LDS allocation -- and only its result bits are dropped.  What that needs is that
+    an LDS read past the allocation never faults.  tests/lds_oob/lds_oob.hip reads from just past a 4 KB allocation up to 2 GB beyond it: no fault,
+    the fill pattern in range, 0 from 64 KB past the end on.  (Just past the end the reads return stale words of the allocation granule's
+    padding, not 0 -- round 5 measured it; the kernels' comments said "reads as zero" until then.  Nothing depends on the value.)"""
     import subprocess
 
     src = synth.DATA.parent / "lds_oob" / "lds_oob.hip"
