@@ -864,7 +864,12 @@ arp_status enqueue_pack_kernels(BatchSlot &sl, const arp_params *params) {
         launch_count(sl.dev, ctx->ws, ctx->stream, prof, ctx->out_cap, true, only);
         launch_fill_ordered(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only);
     } else {
-        launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only, false, ctx->rkey_valid);
+        // (a pack never takes the hole-free sequence of small inputs -- DevAtoms::per_model rules it out in launch_emit_e --: that sequence leaves
+        // result[0] and the capacity flag for the HOST to derive (finish_result), and the split kernels below read result[0] on the device)
+        if (launch_emit(sl.dev, ctx->ws, ctx->out_buf, ctx->out_cap, ctx->stream, prof, only, false, ctx->rkey_valid)) {
+            set_error("internal error: a pack ran the hole-free emit sequence, whose pair count only exists on the host");
+            return ARP_ERR_HIP;
+        }
     }
     launch_pack_split(sl.pa, ctx->ws.result, ctx->out_buf, std::min(ctx->out_cap, ctx->grp_cap), ctx->grp_buf, sl.ordered, ctx->stream);
     HIP_TRY(hipGetLastError());

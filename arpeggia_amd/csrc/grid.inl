@@ -506,12 +506,20 @@ DEVFN uint32_t wave_inclusive_add_u32(uint32_t v) {  // (the scan wave_reduce_u3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
+// Round 5: launched with kScanOneBlocks blocks.  Block b takes the passes b, b + kScanOneBlocks, ...: the usual input is one pass,
+// which block 0 runs exactly as before while the other blocks read the cell count and leave; a sparse or many-model input of the same atom
+// count (up to 8 n + 64 K cells: ~23 passes at 180 000 atoms) no longer runs them one after the other on one CU.  A pass publishes its total
+// as one word {1, total} (the words k_scan_single uses, zeroed by the grid sizing) and adds up the words of the passes before it.
+constexpr uint32_t kScanOneBlocks = 32;  // >= ceil((8 * kScanOneAtoms + 65536 + 1) / kScanOneCells) = 23 passes
 template <bool ZERO_IN>
-__global__ __launch_bounds__(kScanOneThreads) void k_scan_one(uint32_t *in, const uint32_t *n_ptr, uint32_t *out) {
+__global__ __launch_bounds__(kScanOneThreads) void k_scan_one(uint32_t *in, const uint32_t *n_ptr, unsigned long long *part, uint32_t *out) {
     __shared__ uint32_t wave_total[kScanOneThreads / 64];
+    __shared__ uint32_t s_carry;
     const uint32_t n = *n_ptr, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += kScanOneCells) {
+    const uint32_t n_pass = (n + kScanOneCells - 1u) / kScanOneCells;
+    if (blockIdx.x == 0u && n_pass == 0u && threadIdx.x == 0u) out[0] = 0u;  // (no cells: the total)
+    for (uint32_t ps = blockIdx.x; ps < n_pass; ps += gridDim.x) {
+        const uint32_t base = ps * kScanOneCells;
         const uint32_t w0 = base + wave * (kScanOnePer * 256u) + lane * 4u;
         uint4 v[kScanOnePer];
 #pragma unroll
@@ -528,11 +536,27 @@ __global__ __launch_bounds__(kScanOneThreads) void k_scan_one(uint32_t *in, cons
             ex[j] = run + inc - s;
             run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
-        __syncthreads();  // (the previous pass is done with wave_total)
+        __syncthreads();  // (the previous pass of this block is done with wave_total / s_carry)
         if (lane == 0u) wave_total[wave] = run;
         __syncthreads();
-        uint32_t before = carry, pass = 0;
+        uint32_t before = 0, pass = 0;
         for (uint32_t k = 0; k < kScanOneThreads / 64u; k++) { const uint32_t t = wave_total[k]; if (k < wave) before += t; pass += t; }
+        // the passes before this one (none for the usual single pass): their published totals, read as they appear
+        if (n_pass > 1u) {
+            if (threadIdx.x == 0u) __hip_atomic_store(&part[ps], (1ull << 32) | pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 0u) {
+                uint32_t c = 0;
+                for (uint32_t k = lane; k < ps; k += 64u) {
+                    unsigned long long w;
+                    do { w = __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 32) == 0ull);
+                    c += (uint32_t)w;
+                }
+                c = wave_inclusive_add_u32(c);
+                if (lane == 63u) s_carry = c;
+            }
+            __syncthreads();
+            before += s_carry;
+        }
 #pragma unroll
         for (uint32_t j = 0; j < kScanOnePer; j++) {
             const uint32_t i = w0 + j * 256u, o = before + ex[j];
@@ -545,9 +569,8 @@ __global__ __launch_bounds__(kScanOneThreads) void k_scan_one(uint32_t *in, cons
                 if (ZERO_IN) { in[i] = 0u; if (i + 1u < n) in[i + 1u] = 0u; if (i + 2u < n) in[i + 2u] = 0u; }
             }
         }
-        carry += pass;
+        if (ps + 1u == n_pass && threadIdx.x == 0u) out[n] = (n_pass > 1u ? s_carry : 0u) + pass;  // the last pass holds the grand total
     }
-    if (threadIdx.x == 0u) out[n] = carry;
 }
 
 // ---------------------------------------------------------------------------------------------- sort into cells

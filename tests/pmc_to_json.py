@@ -1,7 +1,7 @@
 """profiles/rNN_traffic.json from a PMC summary (tests/pmc_summary.py output): the HBM-side traffic and the instruction-issue figures of the
 dominant kernel, TAGGED WITH THE CONTENT HASH OF THE SOURCES the profiled library was built from (arpeggia_amd/build.py source_hash) --
 bench.py attaches the measurement to its `roofline` object only when that hash equals the running library's.
-Usage: python tests/pmc_to_json.py SUMMARY.txt OUT.json --workload s2 --atoms 1000000 --pairs 28702955 [--kernel 'arp::k_emit<12, 1, false, false>']"""
+Usage: python tests/pmc_to_json.py SUMMARY.txt OUT.json --workload s2 --atoms 1000000 --pairs 28702955 [--kernel 'arp::k_emit<12, 1, false, false, false>']"""
 import argparse
 import importlib.util
 import json
@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("summary"); ap.add_argument("out")
     ap.add_argument("--workload", default="s2"); ap.add_argument("--atoms", type=int, default=1_000_000); ap.add_argument("--pairs", type=int, required=True)
-    ap.add_argument("--kernel", default="arp::k_emit<12, 1, false, false>")
+    ap.add_argument("--kernel", default="arp::k_emit<12, 1, false, false, false>")
     ap.add_argument("--source", default=None, help="path of the summary as committed under profiles/")
     a = ap.parse_args()
     txt = Path(a.summary).read_text()
