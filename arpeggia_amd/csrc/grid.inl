@@ -201,7 +201,7 @@ DEVFN void setup_block(BoxAcc &acc, SetupLds &l, bool publish, GridParams *g, De
         for (uint32_t k = threadIdx.x; k < kTaskCtrWords; k += blockDim.x) task_ctr[k] = 0;  // per-call state of the later kernels
         if (threadIdx.x < 32) result[threadIdx.x] = 0;  // [0..3] the call's results
         // (result + 32 ..: the published chunk totals of k_scan_single, Workspace::result holds kResultWordsAll words)
-        for (uint32_t k = threadIdx.x; k < kScanSingleBlocks; k += blockDim.x) result[kScanPartAt + k] = 0ull;
+        for (uint32_t k = threadIdx.x; k < kScanBlocks; k += blockDim.x) result[kScanPartAt + k] = 0ull;
     }
     box_block_reduce<4>(acc, l.box);
     auto block_max = [&](double b) {  // (of non-negative values: the bit patterns of non-negative doubles order like unsigned integers, high word first)
@@ -465,18 +465,33 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t *in, const
 __global__ __launch_bounds__(kScanThreads) void k_scan_single(uint32_t *in, const uint32_t *n_ptr, unsigned long long *part, uint32_t *out) {
     __shared__ uint32_t lds[kScanThreads / 64 + 1];
     const uint32_t n = *n_ptr;
-    const uint32_t chunk = (n + kScanSingleBlocks - 1) / kScanSingleBlocks;
+    const uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;  // (gridDim.x: kScanSingleBlocks, or kScanBlocks for the cell counts of packs and of inputs beyond 2^20 atoms)
     const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
     uint32_t s = 0, own;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kScanThreads) s += in[i];
     block_exclusive_scan<uint32_t>(s, &own, lds);
     if (threadIdx.x == 0) __hip_atomic_store(&part[blockIdx.x], (1ull << 32) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t before = 0, carry;
-    if (threadIdx.x < blockIdx.x) {  // thread k waits for block k's word (blocks with a smaller index were dispatched earlier)
-        unsigned long long v;
-        do { v = __hip_atomic_load(&part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) == 0ull);
-        before = (uint32_t)v;
+    // thread t waits for the words of blocks t, t + 256, ... (blocks with a smaller index were dispatched earlier); the loads of a round are in
+    // flight together, and only the words that had not appeared yet are asked for again
+    constexpr uint32_t kWordsPer = kScanBlocks / kScanThreads;
+    unsigned long long w[kWordsPer];
+    bool pending = false;
+#pragma unroll
+    for (uint32_t j = 0; j < kWordsPer; j++) {
+        const uint32_t k = threadIdx.x + j * kScanThreads;
+        w[j] = k < blockIdx.x ? __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 32);
     }
+#pragma unroll
+    for (uint32_t j = 0; j < kWordsPer; j++) pending |= (w[j] >> 32) == 0ull;
+    while (pending) {
+        pending = false;
+#pragma unroll
+        for (uint32_t j = 0; j < kWordsPer; j++)
+            if ((w[j] >> 32) == 0ull) { w[j] = __hip_atomic_load(&part[threadIdx.x + j * kScanThreads], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pending |= (w[j] >> 32) == 0ull; }
+    }
+    uint32_t before = 0, carry;
+#pragma unroll
+    for (uint32_t j = 0; j < kWordsPer; j++) before += (uint32_t)w[j];
     __syncthreads();
     block_exclusive_scan<uint32_t>(before, &carry, lds);
     __syncthreads();

@@ -682,7 +682,8 @@ void launch_grid(const DevAtoms &in, const Workspace &ws, hipStream_t st, Profil
     P1();
     P0("grid_scan");
     if (!in.per_model && n <= kScanOneAtoms) hipLaunchKernelGGL(k_scan_one<true>, dim3(kScanOneBlocks), dim3(kScanOneThreads), 0, st, ws.cell_count, (const uint32_t *)&ws.grid->ncells, ws.result + kScanPartAt, ws.cell_start);
-    else hipLaunchKernelGGL(k_scan_single, dim3(kScanSingleBlocks), dim3(kScanThreads), 0, st, ws.cell_count, (const uint32_t *)&ws.grid->ncells, ws.result + kScanPartAt, ws.cell_start);
+    else hipLaunchKernelGGL(k_scan_single, dim3(in.per_model || n > kCidFoldAtoms ? kScanBlocks : kScanSingleBlocks), dim3(kScanThreads), 0, st, ws.cell_count, (const uint32_t *)&ws.grid->ncells,
+                            ws.result + kScanPartAt, ws.cell_start);  // (256 blocks: one round of one word per thread; packs and the largest inputs have tens of MB of cells: 1024)
     P1();
     P0("grid_sort");
     if (ordered) {

@@ -388,6 +388,229 @@ __global__ __launch_bounds__(256) void k_finish_rows(uint32_t n_rows, const uint
     out_sc[p] = sc;
 }
 
+// ---- PDB-sized tables in ONE launch (round 5) -----------------------------------------------------------------------------------------
+// A table of a few thousand rows is a chain of launches that each last 4-5 us whatever they do: bit count, offset scan (2), row expansion, key,
+// rocPRIM's block sort + three merges, tie fix, finish, the copy of the rows -- 54 of 6bft's 134 us were the sort alone.  Up to kSmallRows rows one
+// workgroup does all of it (the launcher takes this path up to kSmallPairs pairs, see device_table): the rows of a pair per set bit of its kind word (complex.rs:217-296) at the offsets of a block-wide scan, the ring rows
+// behind them, the ten sort keys of mod.rs:120-134 merged into one word (as k_row_key's pass 6) with the row index below them -- so that a plain
+// compare-exchange network sorts (keys, position), which is what the stable radix passes of the general path produce --, a bitonic sort of those
+// words in LDS, the tie pass on neighbours (k_tie_fix), the side-chain plane statistics (k_finish_rows), and the finished table written STRAIGHT
+// INTO THE PINNED LANDING BUFFER the host reads after the stream has drained (no copy command).  What does not fit (more rows, keys wider than
+// 64 - kSmallIdxBits bits, a tie run longer than kTieRun) is reported in the header and the general path runs instead.
+constexpr uint32_t kSmallRows = 4096, kSmallThreads = 1024, kSmallIdxBits = 12, kSmallPairs = 2048;
+struct SmallHeader { uint32_t n_rows, status, n_atom_rows, n_ring_rows; };  // status: 0 = done; 1 = too many rows; 2 = a tie run too long; 3 = more ring rows than reserved
+
+// Bitonic sort (ascending) of n_pad = E x (active threads) 64-bit words, thread t holding the E consecutive words t E .. t E + E - 1 in registers.
+// A compare-exchange step at distance j pairs word g with word g ^ j: inside the thread's own registers for j < E, with the same register of
+// thread t ^ (j / E) beyond -- by a wave shuffle while that thread is in the same wave, through LDS (two barriers) only for the steps whose
+// partner sits in another wave: 6 of the 78 steps of 4096 words.  (The first version of k_table_small ran all 91 through LDS, one
+// compare-exchange at a time per thread: 68 us on 6bft's 7236 rows.)
+template <uint32_t E>
+__device__ __forceinline__ void bitonic_sort_block(unsigned long long (&v)[E], unsigned long long *buf, uint32_t n_pad, uint32_t tid) {
+    const uint32_t base = tid * E;
+    const bool active = base < n_pad;
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                unsigned long long other[E];
+                const uint32_t pj = j / E;
+                if (pj < 64u) {
+#pragma unroll
+                    for (uint32_t e = 0; e < E; e++) other[e] = __shfl_xor(v[e], (int)pj);
+                } else {
+                    __syncthreads();  // (the previous exchange's reads are done)
+                    if (active) {
+#pragma unroll
+                        for (uint32_t e = 0; e < E; e++) buf[base + e] = v[e];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t e = 0; e < E; e++) other[e] = active ? buf[(base + e) ^ j] : v[e];
+                }
+                // (j >= E and k > j: bits j and k of word t E + e are those of t E -- one decision per thread and step)
+                const bool keep_min = ((base & k) == 0u) == ((base & j) == 0u);  // ascending stretch and the lower partner, or descending and the upper one
+#pragma unroll
+                for (uint32_t e = 0; e < E; e++) {
+                    const unsigned long long a = v[e], b = other[e];
+                    v[e] = ((a < b) == keep_min) ? a : b;
+                }
+            } else {
+                // the steps inside the thread's own words: all of them at once, with compile-time distances (a register array indexed by the
+                // loop variable j would live in scratch memory: the first blocked version of this sort took 350 us that way)
+#pragma unroll
+                for (uint32_t jj = E / 2u; jj > 0u; jj >>= 1) {
+                    if (jj > j) continue;  // (this merge starts below jj)
+#pragma unroll
+                    for (uint32_t e = 0; e < E; e++) {
+                        if (e & jj) continue;
+                        const bool up = ((base + e) & k) == 0u;
+                        const unsigned long long a = v[e], b = v[e | jj];
+                        const bool swap = (a > b) == up;
+                        v[e] = swap ? b : a; v[e | jj] = swap ? a : b;
+                    }
+                }
+                break;  // (j < E: the rest of this merge was done above)
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSmallThreads) void k_table_small(const arp_pair *pairs, uint32_t n_pairs, const uint4 *ring_rows, const uint32_t *ring_row_count, uint32_t ring_rows_cap,
+                                                               uint4 *rows, uint32_t n_atoms, const EntKey *atom_keys, const EntKey *ring_keys, const uint32_t *ent_rank,
+                                                               const uint32_t *chain_rank, const uint32_t *model, const uint32_t *model_rank, const RingEnt *rings, SortTables tb,
+                                                               const uint32_t *atom_sc_src, const PlaneD *sc_planes, const uint8_t *valid, char *out, unsigned long long *stamps) {
+    __shared__ unsigned long long skey[kSmallRows];     // the sort words (64 KB): exchange buffer of the sort, then the sorted table
+    __shared__ uint16_t sperm[kSmallRows];              // final order: row index per table position
+    __shared__ uint32_t wave_sum[kSmallThreads / 64];
+    __shared__ uint32_t s_flag;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    SmallHeader *head = reinterpret_cast<SmallHeader *>(out);
+    const uint32_t n_ring_rows = ring_row_count ? *ring_row_count : 0u;
+    if (tid == 0u) s_flag = 0u;
+    auto stamp = [&](int k) { if (stamps && tid == 0u) stamps[k] = wall_clock64(); };  // (arp_debug_set("timing", 1): where the launch's time goes, 100 MHz ticks)
+    stamp(0);
+    // 1. rows per pair, their offsets (thread t: pairs t kPer .. in order, so the offsets are those of the general path's scan); all of a thread's
+    // pairs are requested before the first is looked at -- one workgroup has nothing else to hide a round trip to memory behind
+    constexpr uint32_t kPer = kSmallRows / kSmallThreads;
+    uint4 pr[kPer];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; u++) {
+        const uint32_t p = tid * kPer + u;
+        pr[u] = reinterpret_cast<const uint4 *>(pairs)[p < n_pairs ? p : 0u];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; u++) {
+        if (tid * kPer + u >= n_pairs) pr[u].w = 0u;
+        mine += (uint32_t)__popc(pr[u].w);
+    }
+    uint32_t inc = mine;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off); if (lane >= (uint32_t)off) inc += t; }
+    if (lane == 63u) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, n_atom_rows = 0;
+    for (uint32_t k = 0; k < kSmallThreads / 64u; k++) { const uint32_t t = wave_sum[k]; if (k < wave) before += t; n_atom_rows += t; }
+    const uint32_t n_rows = n_atom_rows + n_ring_rows;
+    if (n_rows > kSmallRows || n_ring_rows > ring_rows_cap) {
+        if (tid == 0u) *head = SmallHeader{n_rows, n_ring_rows > ring_rows_cap ? 3u : 1u, n_atom_rows, n_ring_rows};
+        return;
+    }
+    // 2. the rows (global scratch: 128 KB would not fit LDS next to the sort words), atom rows first, ring rows behind them
+    {
+        uint32_t o = before + inc - mine;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++)
+            for (uint32_t b = pr[u].w; b; b &= b - 1u, ++o) rows[o] = make_uint4(pr[u].x, pr[u].y, pr[u].z, (uint32_t)(__ffs((int)b) - 1));
+        for (uint32_t k = tid; k < n_ring_rows; k += kSmallThreads) rows[n_atom_rows + k] = ring_rows[k];
+    }
+    __syncthreads();  // (workgroup-scope: the rows written above are read by other waves of this block below)
+    stamp(1);
+    // 3. one sort word per row: the ten keys (k_row_key pass 6) above the row's index; padding sorts last.  Thread t holds the words of rows
+    // t E .. t E + E - 1 (E = n_pad / 1024, at least 1); the gathers of a thread's rows are in flight together.
+    auto chain_of = [&](uint32_t e) { return e < n_atoms ? (uint32_t)chain_rank[e] : rings[e - n_atoms].chain_rank; };
+    uint32_t n_pad = 64u;
+    while (n_pad < n_rows) n_pad <<= 1;
+    const uint32_t E = n_pad > kSmallThreads ? n_pad / kSmallThreads : 1u;
+    unsigned long long v[kPer];
+    {
+        uint4 r[kPer];
+#pragma unroll
+        for (uint32_t e = 0; e < kPer; e++) { const uint32_t p = tid * E + e; r[e] = rows[(e < E && p < n_rows) ? p : 0u]; }
+#pragma unroll
+        for (uint32_t e = 0; e < kPer; e++) {
+            const uint32_t p = tid * E + e;
+            v[e] = ~0ull;
+            if (e < E && p < n_rows) {
+                const uint32_t mr = r[e].x < n_atoms ? model_rank[model[r[e].x]] : rings[r[e].x - n_atoms].model_rank;
+                unsigned long long k = ((((unsigned long long)mr << tb.chain_bits) | chain_of(r[e].x)) << tb.chain_bits) | chain_of(r[e].y);
+                k = (k << tb.rank_bits) | ent_rank[r[e].x];
+                k = (k << (tb.rank_bits + 5u)) | ((unsigned long long)ent_rank[r[e].y] << 5) | tb.name_rank[r[e].w & 31u];
+                v[e] = (k << kSmallIdxBits) | p;
+            }
+        }
+    }
+    stamp(2);
+    // 4. the sort
+    switch (E) {
+        case 1: { unsigned long long w1[1] = {v[0]}; bitonic_sort_block<1>(w1, skey, n_pad, tid); v[0] = w1[0]; break; }
+        case 2: { unsigned long long w2[2] = {v[0], v[1]}; bitonic_sort_block<2>(w2, skey, n_pad, tid); v[0] = w2[0]; v[1] = w2[1]; break; }
+        default: static_assert(kPer == 4, "one instantiation per words-per-thread count"); bitonic_sort_block<kPer>(v, skey, n_pad, tid);
+    }
+    __syncthreads();  // (the sort's last exchange is done with skey)
+#pragma unroll
+    for (uint32_t e = 0; e < kPer; e++)
+        if (e < E && tid * E + e < n_pad) skey[tid * E + e] = v[e];
+    __syncthreads();
+    stamp(3);
+    // 5. rows whose ten keys tie take the place their (from_insertion, to_insertion, distance, position) earns inside their run (k_tie_fix)
+    auto ins_of = [&](uint32_t e) { return e < n_atoms ? atom_keys[e].icode : ring_keys[e - n_atoms].icode; };
+    constexpr unsigned long long kIdxMask = (1ull << kSmallIdxBits) - 1ull;
+    for (uint32_t p = tid; p < n_rows; p += kSmallThreads) {
+        auto same = [&](uint32_t a, uint32_t b) { return (skey[a] >> kSmallIdxBits) == (skey[b] >> kSmallIdxBits); };
+        const uint32_t me = (uint32_t)(skey[p] & kIdxMask);
+        const bool tie_prev = p > 0u && same(p - 1u, p), tie_next = p + 1u < n_rows && same(p, p + 1u);
+        if (!tie_prev && !tie_next) { sperm[p] = (uint16_t)me; continue; }
+        uint32_t lo = p, hi = p + 1u;
+        while (lo > 0u && p - lo < kTieRun && same(lo - 1u, lo)) lo--;
+        while (hi < n_rows && hi - p < kTieRun && same(hi - 1u, hi)) hi++;
+        if (p - lo >= kTieRun || hi - p >= kTieRun) { s_flag = 1u; continue; }
+        auto tie_key = [&](uint32_t q, unsigned long long *ins, uint32_t *dist) {
+            const uint4 r = rows[(uint32_t)(skey[q] & kIdxMask)];
+            *ins = ((unsigned long long)ins_of(r.x) << 32) | ins_of(r.y); *dist = r.z;
+        };
+        unsigned long long my_ins; uint32_t my_dist;
+        tie_key(p, &my_ins, &my_dist);
+        uint32_t ahead = 0;
+        for (uint32_t q = lo; q < hi; q++) {
+            if (q == p) continue;
+            unsigned long long ins; uint32_t dist;
+            tie_key(q, &ins, &dist);
+            const bool less = ins != my_ins ? ins < my_ins : (dist != my_dist ? dist < my_dist : q < p);
+            ahead += less ? 1u : 0u;
+        }
+        sperm[lo + ahead] = (uint16_t)me;
+    }
+    __syncthreads();
+    if (s_flag) {
+        if (tid == 0u) *head = SmallHeader{n_rows, 2u, n_atom_rows, n_ring_rows};
+        return;
+    }
+    stamp(4);
+    // 6. final order + the side-chain plane statistics (k_finish_rows), straight into the host's landing buffer; again every load of a thread's
+    // rows is asked for before the first is used
+    uint4 *out_rows = reinterpret_cast<uint4 *>(out + 16);
+    float4 *out_sc = reinterpret_cast<float4 *>(out + 16 + (size_t)n_rows * 16u);
+    {
+        uint4 r[kPer];
+        uint32_t s1[kPer], s2[kPer];
+        uint8_t ok[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) { const uint32_t p = tid + u * kSmallThreads; r[u] = rows[p < n_rows ? sperm[p] : 0u]; }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) {
+            s1[u] = r[u].x < n_atoms ? atom_sc_src[r[u].x] : rings[r[u].x - n_atoms].sc_src;
+            s2[u] = r[u].y < n_atoms ? atom_sc_src[r[u].y] : rings[r[u].y - n_atoms].sc_src;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) ok[u] = (s1[u] != ARP_NONE && s2[u] != ARP_NONE) ? (uint8_t)(valid[s1[u]] & valid[s2[u]] & 2u) : (uint8_t)0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) {
+            const uint32_t p = tid + u * kSmallThreads;
+            if (p >= n_rows) continue;
+            out_rows[p] = r[u];
+            float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) {
+                const PlaneD p1 = sc_planes[s1[u]], p2 = sc_planes[s2[u]];
+                sc = make_float4((float)point_dist_d(p1, p2.c), (float)plane_dihedral_d(p1, p2), (float)point_angle_d(p1, p2.c), 1.0f);
+            }
+            out_sc[p] = sc;
+        }
+    }
+    __syncthreads();
+    stamp(5);
+    if (tid == 0u) *head = SmallHeader{n_rows, 0u, n_atom_rows, n_ring_rows};
+}
+
 // ---- host orchestration ----------------------------------------------------------------------------------------------
 namespace {
 struct Bump {  // carve a scratch block (256-byte aligned pieces)
@@ -500,11 +723,22 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
     if (nr && derive) hipLaunchKernelGGL(k_fit_planes, grid(nr, 128), dim3(128), 0, st, (uint32_t)nr, (const uint32_t *)ds.res_atom_ptr, (const uint32_t *)ds.res_atom_idx,
                                (const uint8_t *)ds.plane_bits, (const double *)ds.x, (const double *)ds.y, (const double *)ds.z, ring_pl, sc_pl, valid);
     // atom-atom rows: bit count -> offsets -> rows (after the total is known)
-    hipLaunchKernelGGL(k_count_bits, grid(n_pairs + 1, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, bits, counters);  // (also clears the counters)
-    if (n_pairs) {
-        size_t tmp = cub_scan;
-        TRY_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, (const uint32_t *)bits, first, (int)n_pairs + 1, st));
-    }
+    // PDB-sized tables (at most kSmallRows pairs, hence checked rows, and keys that leave kSmallIdxBits bits of the sort word) take the
+    // one-launch path below; its kernel counts and scans the bits itself, so only the counters are cleared here
+    // (measured on 6bft, 7236 rows: the one workgroup sorts for 68 us -- n log^2 n compare-exchanges on ONE compute unit -- and gathers for 40 more, which is
+    // no faster than the dozen chip-wide launches it replaces: 0.32 against 0.29 ms per warm call; on 1ubq, 532 rows, the whole kernel is 19 us and the
+    // call 0.13 against 0.15 ms.  So the one-launch path takes tables of up to kSmallPairs pairs; the kernel itself holds kSmallRows rows.)
+    bool small_try = n_pairs <= kSmallPairs;
+    auto launch_bits = [&]() -> arp_status {
+        hipLaunchKernelGGL(k_count_bits, grid(n_pairs + 1, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, bits, counters);  // (also clears the counters)
+        if (n_pairs) {
+            size_t tmp = cub_scan;
+            TRY_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp, (const uint32_t *)bits, first, (int)n_pairs + 1, st));
+        }
+        return ARP_OK;
+    };
+    if (!small_try) { if ((s = launch_bits()) != ARP_OK) return s; }
+    else if (n_rings || derive) TRY_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(uint32_t), st));
     // entity ranks: sort the entities by (chain, resi, altloc, atomi), least significant key first; rank = number of key changes since the
     // chain's first entity
     if (derive) {
@@ -542,17 +776,71 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
         ds.max_ent_rank = max_rank;
     }
     lap("planes+bits+ranks");
-    // f1: the ring rows, into a buffer of their own (their number is bounded up front) -- so that the ONE read-back below brings both the
-    // atom-row and the ring-row count and the row buffers are sized exactly, without a second wait for the device.
-    if (n_rings) {
+    auto width = [](uint64_t v) { uint32_t b = 1; while (b < 32 && (1ull << b) < v) b++; return b; };  // bits that hold 0 .. v-1
+    SortTables tb{};
+    {
+        int o[ARP_N_INTERACTIONS];
+        for (int k = 0; k < ARP_N_INTERACTIONS; k++) o[k] = k;
+        std::sort(o, o + ARP_N_INTERACTIONS, [](int a, int c) { return strcmp(arp_interaction_name(a), arp_interaction_name(c)) < 0; });
+        for (int k = 0; k < ARP_N_INTERACTIONS; k++) tb.name_rank[o[k]] = (uint8_t)k;
+    }
+    tb.rank_bits = width((uint64_t)ds.max_ent_rank + 1); tb.chain_bits = width(std::max<uint64_t>(ds.n_chains, 1));
+    if (small_try && width(std::max<uint64_t>(ds.n_models, 1)) + 2 * tb.chain_bits + 2 * tb.rank_bits + 5 + kSmallIdxBits > 64) {
+        small_try = false;  // (the ten keys + a row index do not fit one word: the general path, from its first kernel)
+        if ((s = launch_bits()) != ARP_OK) return s;
+    }
+    auto launch_rings = [&]() {
         // the cell list of the pair pass that has just run on this context, on these very arrays
         const GridParams *gridp = nullptr; const uint32_t *cell_start = nullptr; const Fat *fat = nullptr;
         if (!context_grid(ctx, ds.x, ds.n, &gridp, &cell_start, &fat)) { set_error("internal error: the context holds no cell list of this structure"); return ARP_ERR_HIP; }
         hipLaunchKernelGGL(k_ring_atom, dim3((uint32_t)n_rings), dim3(64), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (uint32_t)n,
                            (const int32_t *)ds.model_serial_of, gridp, cell_start, fat, dist_cutoff, ring_rows, counters, (uint32_t)ring_rows_cap, ring_pts,
-                           n_pairs ? (const uint32_t *)(first + n_pairs) : (const uint32_t *)nullptr);
+                           n_pairs && !small_try ? (const uint32_t *)(first + n_pairs) : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(k_ring_ring, dim3((uint32_t)n_rings), dim3(256), 0, st, (uint32_t)n_rings, (const RingEnt *)d_rings, (const PlaneD *)ring_pl, (const RingPoint *)ring_pts, (uint32_t)n, ring_rows,
                            counters, (uint32_t)ring_rows_cap);
+        return ARP_OK;
+    };
+    if (small_try) {
+        // ONE launch behind the ring kernels, the table written straight into the pinned landing block, one wait for the stream
+        const uint64_t land = 16 + (uint64_t)kSmallRows * 32 + 256;
+        char *dev2 = nullptr, *pin2 = nullptr;
+        if ((s = context_scratch(ctx, 1, al((uint64_t)kSmallRows * 16) + 4096, land, &dev2, &pin2)) != ARP_OK) return s;
+        if (n_rings && (s = launch_rings()) != ARP_OK) return s;
+        hipLaunchKernelGGL(k_table_small, dim3(1), dim3(kSmallThreads), 0, st, pairs_dev, (uint32_t)n_pairs, (const uint4 *)ring_rows, n_rings ? (const uint32_t *)counters : (const uint32_t *)nullptr,
+                           (uint32_t)ring_rows_cap, reinterpret_cast<uint4 *>(dev2), (uint32_t)n, (const EntKey *)ds.ent_key, (const EntKey *)d_ring_keys, (const uint32_t *)ent_rank,
+                           (const uint32_t *)ds.chain_rank, (const uint32_t *)ds.model, (const uint32_t *)ds.model_rank, (const RingEnt *)d_rings, tb, (const uint32_t *)ds.atom_sc_src,
+                           (const PlaneD *)sc_pl, (const uint8_t *)valid, pin2, timing ? reinterpret_cast<unsigned long long *>(pin2 + land - 128) : (unsigned long long *)nullptr);
+        TRY_HIP(hipGetLastError());
+        TRY_HIP(hipStreamSynchronize(st));
+        SmallHeader head;
+        memcpy(&head, pin2, sizeof head);
+        lap("one-launch table");
+        if (timing) {
+            unsigned long long t[6];
+            memcpy(t, pin2 + land - 128, sizeof t);
+            fprintf(stderr, "      k_table_small (us): rows %.1f  keys %.1f  sort %.1f  ties %.1f  finish %.1f\n", (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01,
+                    (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01);
+        }
+        if (head.status == 0u) {
+            out->n = head.n_rows;
+            const size_t row_bytes = (size_t)head.n_rows * 16;
+            char *heap = (char *)malloc(2 * row_bytes + 64);
+            if (!heap) { set_error("out of host memory"); return ARP_ERR_OOM; }
+            out->owner = std::shared_ptr<char>(heap, [](char *q) { free(q); });
+            memcpy(heap, pin2 + 16, 2 * row_bytes);
+            out->rows = reinterpret_cast<TableRow *>(heap);
+            out->sc = reinterpret_cast<TableSc *>(heap + row_bytes);
+            lap("unpack");
+            return ARP_OK;
+        }
+        if (head.status == 3u) { set_error("internal error: more ring rows than reserved (%u > %llu)", head.n_ring_rows, (unsigned long long)ring_rows_cap); return ARP_ERR_HIP; }
+        small_try = false;  // more rows than one workgroup sorts, or a long tie run: the general path, from its first kernel
+        if ((s = launch_bits()) != ARP_OK) return s;
+    }
+    // f1: the ring rows, into a buffer of their own (their number is bounded up front) -- so that the ONE read-back below brings both the
+    // atom-row and the ring-row count and the row buffers are sized exactly, without a second wait for the device.
+    if (n_rings) {
+        if ((s = launch_rings()) != ARP_OK) return s;
     }
     // how many rows?  (one small read-back: the row buffers are sized by it)
     counts_host[0] = counts_host[3] = 0u;
@@ -583,18 +871,9 @@ arp_status device_table(arp_context *ctx, DevStructure &ds, const std::vector<Ri
     char *cub_tmp2 = b.take<char>(cub_sort_rows);
     if (n_pairs + n_ring_rows) hipLaunchKernelGGL(k_expand_rows, grid(n_pairs + n_ring_rows, 256), dim3(256), 0, st, pairs_dev, (uint32_t)n_pairs, (const uint32_t *)first, rows,
                                                   (uint32_t)rows_cap, (const uint4 *)ring_rows, n_ring_rows, n_atom_rows);  // (the ring rows behind the atom rows)
-    SortTables tb{};
-    {
-        int o[ARP_N_INTERACTIONS];
-        for (int k = 0; k < ARP_N_INTERACTIONS; k++) o[k] = k;
-        std::sort(o, o + ARP_N_INTERACTIONS, [](int a, int c) { return strcmp(arp_interaction_name(a), arp_interaction_name(c)) < 0; });
-        for (int k = 0; k < ARP_N_INTERACTIONS; k++) tb.name_rank[o[k]] = (uint8_t)k;
-    }
     // The sort: stable radix passes over row indices, least significant key first.  The entity ranks, interaction, chains and model go
     // into ONE key when their actual widths fit 64 bits (else two or three passes); rows whose ten keys tie are put in order afterwards
     // (k_tie_fix).  `long_way`: the tie-breaking keys -- insertion codes (skipped when no atom carries one), distance -- as passes of their own.
-    auto width = [](uint64_t v) { uint32_t b = 1; while (b < 32 && (1ull << b) < v) b++; return b; };  // bits that hold 0 .. v-1
-    tb.rank_bits = width((uint64_t)ds.max_ent_rank + 1); tb.chain_bits = width(std::max<uint64_t>(ds.n_chains, 1));
     auto sort_and_finish = [&](bool long_way) -> arp_status {
         const uint32_t model_bits = width(std::max<uint64_t>(ds.n_models, 1)), top = model_bits + 2 * tb.chain_bits;
         int plan[5], end_bit[5], n_pass = 0;

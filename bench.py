@@ -138,6 +138,7 @@ def record_hash_device(torch, out, n) -> int:
 
 
 LAST: dict = {}  # what the most recent measure_resident() saw besides its return values: first_call_ms, pair_hash
+WANT_HASH = False  # set by main() when the CPU-baseline leg will compare the records (the hash runs torch kernels: kept out of profiler runs)
 
 
 def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, profile_steps, barrier, check=True):
@@ -176,7 +177,8 @@ def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, p
     got = ctx.result()
     assert not check or got == n_pairs
     dev_ms = ev0.elapsed_time(ev1) / steps
-    LAST["pair_hash"] = record_hash_device(torch, out, got)  # what the LAST timed step left in the buffer
+    if WANT_HASH:
+        LAST["pair_hash"] = record_hash_device(torch, out, got)  # what the LAST timed step left in the buffer
     # per-kernel durations (HIP events on the same stream, separate pass so they do not perturb the timed region)
     acc: dict = {}
     if profile_steps:
@@ -374,6 +376,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    global WANT_HASH
+    WANT_HASH = world == 1 and not args.no_cpu_baseline
     prm = aa.default_params(0.1, 6.5, deterministic=args.deterministic, contacts_only=args.contacts_only,
                             residue_runs={"auto": None, "on": True, "off": False}[args.residue_runs])
     check = not args.no_check

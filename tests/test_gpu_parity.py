@@ -1093,6 +1093,23 @@ def test_table_on_stress_structure_matches_oracle_table(ctx, tmp_path):
         _lines_close(_table_lines(cols), want)
 
 
+@pytest.mark.parametrize("n_res", [20, 70, 130, 200])
+def test_small_tables_in_one_launch_match_the_oracle(ctx, tmp_path, n_res):
+    """Round 5: tables of up to 2048 contact pairs are counted, expanded, keyed, sorted (a bitonic network over one workgroup: 1, 2 or 4 sort words per
+    thread), tie-fixed and finished by ONE kernel (k_table_small) that writes into the host's landing buffer.  Graded sizes around the words-per-thread
+    steps, with hydrogens, altlocs and two chain groups, row for row against the oracle's table; and the same structure twice in a row (the
+    landing buffer and the counters are reused)."""
+    rec = synth.gen_stress(n_res=n_res, seed=500 + n_res, n_chains=2)
+    p = tmp_path / "small.pdb"
+    synth.write_pdb(rec, p)
+    s, o = aa.load_model(p), ob.Structure.load(p)
+    for groups in ("/", "A/B"):
+        want = ob.rows_to_csv_lines(o.get_contacts(groups, 0.1, 6.5))
+        for _ in range(2):
+            _lines_close(_table_lines(ctx.get_contacts(s, groups, 0.1, 6.5)), want)
+    assert len(want) > 0
+
+
 def test_table_with_long_runs_of_tied_sort_keys(ctx, tmp_path):
     """Rows whose ten sort keys tie are ordered by (from_insertion, to_insertion, distance).  Here 26 residues at a time share their residue
     NUMBER (insertion codes A..Z) and every atom of the file carries serial 5, so all rows between such residues with the same interaction tie:
