@@ -138,6 +138,8 @@ struct arp_context {
     bool have_params = false;
     DevParams *params_on_device = nullptr;  // the workspace block that holds the current parameters (upload_params); reset with the workspace
     hipStream_t params_stream = nullptr;    // ... uploaded on this stream (a caller who swaps streams gets a fresh upload, ordered on the new one)
+    hipEvent_t params_ev = nullptr;         // recorded behind the last upload of h_params: the block is rewritten only after that copy has run
+    bool params_ev_armed = false;
     uint64_t last_capacity = 0;
     bool pending = false;
     char *scr_dev[2] = {nullptr, nullptr}, *scr_pin[2] = {nullptr, nullptr};  // table path: two grow-only scratch blocks (device / pinned)
@@ -265,6 +267,7 @@ extern "C" void arp_context_destroy(arp_context *ctx) {
     if (ctx->grp_buf) (void)hipFree(ctx->grp_buf);
     if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
     for (int k = 0; k < 2; k++) { if (ctx->bounce[k]) (void)hipHostFree(ctx->bounce[k]); if (ctx->bounce_ev[k]) (void)hipEventDestroy(ctx->bounce_ev[k]); }
+    if (ctx->params_ev) (void)hipEventDestroy(ctx->params_ev);
     if (ctx->h_params) (void)hipHostFree(ctx->h_params);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->prof.created) for (int k = 0; k < Profiler::kMax; k++) { (void)hipEventDestroy(ctx->prof.ev0[k]); (void)hipEventDestroy(ctx->prof.ev1[k]); }
@@ -346,8 +349,9 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
     // The device copy is uploaded when the parameters (or the workspace it lives in) change, not per call: the three fields a call derives
     // from its input (DevParams::r2, r2f, s_cov_max) are rewritten by every call's grid sizing from fields that nothing on the device writes.
     if (!ctx->have_params || memcmp(&ctx->last_params, p, sizeof *p) != 0) {
-        // the pinned buffer may still be in flight from the previous upload
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // the pinned block may still be in flight from the previous upload: wait for THAT copy (an event behind it), not for the stream -- a batch
+        // whose flags differ from the previous call's used to drain the 52 MB input copy it had just queued (~1 ms per pack, profiles/r05_experiments.txt)
+        if (ctx->params_ev_armed) HIP_TRY(hipEventSynchronize(ctx->params_ev));
         make_dev_params(*p, ctx->h_params);
         ctx->last_params = *p;
         ctx->have_params = true;
@@ -355,6 +359,9 @@ static arp_status upload_params(arp_context *ctx, const arp_params *p) {
     }
     if (ctx->params_on_device != ctx->ws.params || ctx->params_stream != ctx->stream) {
         HIP_TRY(hipMemcpyAsync(ctx->ws.params, ctx->h_params, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+        if (!ctx->params_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->params_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->params_ev, ctx->stream));
+        ctx->params_ev_armed = true;
         ctx->params_on_device = ctx->ws.params; ctx->params_stream = ctx->stream;
     }
     return ARP_OK;
@@ -924,6 +931,7 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
     });
     lap("launch: assemble (host)");
     HIP_TRY(hipMemcpyAsync(dev, pin, lay.upload, hipMemcpyHostToDevice, ctx->stream));
+    lap("launch:   H2D call");
     auto at = [&](int k) { return dev + lay.off[k]; };
     PackArrays &pa = sl.pa;
     pa.n = (uint32_t)pk.n; pa.n_res = (uint32_t)pk.n_res; pa.n_h = (uint32_t)pk.n_h; pa.K = (uint32_t)K;
@@ -932,6 +940,7 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
     pa.res_h_idx = (uint32_t *)at(PackLayout::RES_H_IDX); pa.n_models = (uint32_t *)at(PackLayout::N_MODELS); pa.status = (uint32_t *)at(PackLayout::STATUS);
     pa.count = (unsigned long long *)at(PackLayout::COUNT); pa.offset = (unsigned long long *)at(PackLayout::OFFSET); pa.cursor = (unsigned long long *)at(PackLayout::CURSOR);
     launch_pack_fix(pa, ctx->stream);
+    lap("launch:   pack_fix calls");
     DevAtoms &d = sl.dev;
     d = DevAtoms{};
     d.n = pa.n; d.n_res = pa.n_res; d.per_model = 1u;
@@ -941,8 +950,9 @@ arp_status launch_pack(BatchSlot &sl, const arp_atoms *const *atoms, const arp_p
     d.res_id = pa.res_id; d.res_h_ptr = pa.res_h_ptr; d.res_h_idx = pa.res_h_idx; d.res_cb = pa.res_cb; d.res_sg = pa.res_sg;
     sl.ordered = false;  // (ordered calls are never packed, see the plan)
     if ((s = upload_params(ctx, params)) != ARP_OK) return s;
+    lap("launch:   params");
     if ((s = enqueue_pack_kernels(sl, params)) != ARP_OK) return s;
-    lap("launch: enqueue");
+    lap("launch: enqueue (kernels)");
     sl.in_flight = true;
     return ARP_OK;
 }
