@@ -234,6 +234,38 @@ def test_randomised_structures_and_parameters(ctx, case):
         assert_pairs_equal(only, want[want["kind"] != 0], what + " contacts-only")
 
 
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("ARP_FUZZ_MID_CASES", "6"))))  # ARP_FUZZ_MID_CASES=60 for a soak run
+def test_randomised_mid_size_structures_through_both_kernel_families(ctx, case):
+    """The randomised structures above stay below 20 480 atoms (the 4-wave kernels).  These are large enough for the 12-wave kernels with the
+    four-way task split -- with and without hydrogens, several chains and models, random chain groups and parameters -- and go through the plain
+    and the residue-rule kernels (round 5), all candidates and contacts only, against the oracle."""
+    rng = np.random.default_rng(7100 + case)
+    n_res = int(rng.integers(2800, 6000))
+    hydrogens = bool(rng.integers(0, 2))
+    n_chains = int(rng.integers(1, 6))
+    kw = dict(n_res=n_res if not hydrogens else n_res // 2 + 1400, seed=900 + case, box=float(rng.uniform(60.0, 110.0)), hydrogens=hydrogens,
+              n_models=int(rng.integers(1, 3)), n_chains=n_chains, altlocs=bool(rng.integers(0, 4) == 0))
+    chains = [chr(ord("A") + c) for c in range(n_chains)]
+    pick = lambda: ",".join(sorted(rng.choice(chains, size=int(rng.integers(1, n_chains + 1)), replace=False)))
+    groups = ["/", "/", pick() + "/", pick() + "/" + pick()][int(rng.integers(0, 4))]
+    vdw_comp, cutoff = float(rng.choice([0.0, 0.1, 0.3])), float(rng.choice([4.5, 5.0, 6.5, 8.0]))
+    rec = synth.gen_stress(**kw)
+    prod = aa.Structure.from_records(rec)
+    orc = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False)
+    try:
+        want = orc.atomic_contacts(groups, vdw_comp, cutoff)
+    except ob.OracleError:  # a CYS SG..SG pair without CB (the reference panics): the product must refuse too
+        with pytest.raises(aa.ArpeggiaError):
+            ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff))
+        return
+    what = f"{kw} groups={groups} c={vdw_comp} d={cutoff}"
+    assert prod.n_atoms > 20480, what
+    for runs in (True, False):
+        for only in (False, True):
+            got = ctx.atomic_contacts(prod.view(groups), aa.default_params(vdw_comp, cutoff, contacts_only=only, residue_runs=runs))
+            assert_pairs_equal(got, want[want["kind"] != 0] if only else want, f"{what} residue_runs={runs} only={only}")
+
+
 def test_hydrogen_rich_medium_structure(ctx):
     # 5000 residues with explicit hydrogens (~63k atoms): the deferred probe pass carries a large share of the pairs
     rec = synth.gen_stress(n_res=5000, seed=77, box=28.0 * (5000 / 400.0) ** (1.0 / 3.0))
