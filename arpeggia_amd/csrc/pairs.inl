@@ -110,7 +110,8 @@ DEVFN uint4 *emit_slot(const EmitTarget &tg, unsigned long long pos, unsigned lo
 // (pos1); waves that arrive while it does so sleep on the LDS word until the new chunk is published.
 struct Slots { unsigned long long pos0, pos1; uint32_t n0; };
 DEVFN unsigned long long wave_first_u64(unsigned long long v) {
-    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+    // (the builtin returns int: the casts keep the low word from being sign-extended over the high one -- harmless while positions stay below 2^31, wrong beyond)
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 // Only the LDS atomic itself runs in lane 0; everything derived from its (broadcast) result is wave-uniform, so the
 // position arithmetic lands on the scalar unit instead of costing vector issue slots for one live lane.

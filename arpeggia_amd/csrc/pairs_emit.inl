@@ -262,6 +262,53 @@ DEVFN void stage_copy_e(const uint4 *buf, uint32_t n, unsigned long long pos, co
     }
     wave_lds_fence();  // ... before the buffer is written again
 }
+// The hole-free sequence of inputs between the 4-wave kernels' range and the chip-filling ones (k_emit<.., STAGE>, round 5): the 12-wave blocks have
+// no LDS to stage in, so a wave's records go to a region of its OWN in the engine's scratch block (kWaveStageRecords records, written with plain
+// stores so that they stay in the L2 / Infinity Cache) and are copied to their final places when the wave has no task left -- the places of a
+// whole block at once, from the global record counter (one returning atomic per block), or of one wave when its region fills up.  No chunks, no
+// holes, no fix-up launch (13 us of an 80 us call at 10^5 atoms).  Only the wave itself ever touches its region: nothing has to become visible
+// to another wave, and the copy waits for the wave's own stores (s_waitcnt vmcnt(0)) and reads the region past the vector L1 (device-scope loads:
+// a region that was flushed once and refilled may still have its old lines there).  A final place beyond the caller's capacity is dropped, not
+// spilled into the scratch block (which holds other waves' regions); the count goes on and tells the host how large a buffer the list needs.
+constexpr uint32_t kWaveStageRecords = 1024;
+DEVFN void stage_copy_g(const uint4 *buf, uint32_t n, unsigned long long pos, const EmitTarget &tg, uint32_t lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // four records per lane and trip, every load of a trip in flight before the first is waited for (the first version read one record per trip
+    // through two device-scope atomic loads: ~2 us per trip, 16 us to empty a region -- the kernel was slower than the fix-up launch it saved)
+    constexpr uint32_t kU = 4;
+    for (uint32_t k0 = 0; k0 < n; k0 += 64u * kU) {
+        u32x4 r[kU];
+#pragma unroll
+        for (uint32_t u = 0; u < kU; u++) {
+            const uint4 *src = buf + min(k0 + 64u * u + lane, n - 1u);
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[u]) : "v"(src) : "memory");  // (sc1: past the vector L1, from the L2)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
+#pragma unroll
+        for (uint32_t u = 0; u < kU; u++) {
+            const uint32_t k = k0 + 64u * u + lane;
+            if (k < n && pos + k < tg.capacity) store_record(reinterpret_cast<uint4 *>(tg.out) + (pos + k), make_uint4(r[u].x, r[u].y, r[u].z, r[u].w));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... before the region is written again
+}
+DEVFN void stage_flush_g(StageRef &sg, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(sg.n);
+    if (n == 0u) return;
+    const Slots sl = alloc_direct(&result[2], n, lane);
+    stage_copy_g(sg.buf, n, sl.pos0, tg, lane);
+    sg.n = 0u;
+}
+// one plain (cached) 16-byte record store per lane of m: scalar base + 32-bit lane offset -- the staged records are read again (lm_store_records: nt)
+DEVFN void lm_store_records_cached(lmask m, uint4 *base_v, uint32_t byte_off, const u32x4 &rec) {
+    lmask save;
+    // (the wave's region: wave-uniform by construction, but derived from threadIdx -- say so, the store wants its base in a scalar register pair)
+    const uintptr_t bv = (uintptr_t)base_v;
+    // (the builtin returns int: without the casts the low half is SIGN-extended into the high one -- a region above a 2 GB boundary then faults)
+    uint4 *base = (uint4 *)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bv >> 32)) << 32) | (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bv));
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(m), "v"(byte_off), "v"(rec), "s"(base) : "memory");
+}
 DEVFN void stage_flush_e(StageRef &sg, const EmitTarget &tg, unsigned long long *result, uint32_t lane) {
     const uint32_t n = __builtin_amdgcn_readfirstlane(sg.n);
     if (n == 0u) return;
@@ -307,7 +354,7 @@ template <bool FULL, bool ONLY, uint32_t CHUNK>
 DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &tb, WaveLdsE &w, BlockLds &bl, uint32_t count, uint32_t slot0,
                           const EmitTarget &tg, uint32_t cap_chunks, unsigned long long *result, uint32_t lane, uint32_t wflags, uint32_t probe_bits, StageRef &sg,
                           const DevAtoms &in, const Sorted &so, const ProbeParamsE &pe) {
-    constexpr bool DIRECT = CHUNK == 1u;
+    constexpr bool DIRECT = CHUNK == 1u, STAGE = CHUNK == 2u;  // (CHUNK 1 / 2: the hole-free sequences -- records staged per wave in LDS / in the wave's scratch region)
     count = __builtin_amdgcn_readfirstlane(count);
     const uint32_t e = g.e, hl = e >> kESlotBits, nb = e & kESlotMask;
     const u32x4 bxy = g.bxy, bzp = g.bzp;
@@ -346,7 +393,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
     u32x2 a_old = {0u, 0u};
     if (!ONLY) {
         if (__builtin_expect(n_rec == 0u, 0)) return;
-        if (!DIRECT) a_old = alloc_issue_e(bl.alloc_state, n_rec);
+        if (!DIRECT && !STAGE) a_old = alloc_issue_e(bl.alloc_state, n_rec);
     }
     // distance levels: Le against the element pair's bounds {vdw, cov, clash}, Lg against the fixed ones {4.5, 4.0, 3.5}; L = 4 Le + Lg.
     // Only the van-der-Waals bound on the common path -- a distance below the covalent or the clash bound of ITS
@@ -417,7 +464,7 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
                                      lm_gt_u32_sv(4097u, low - (0x10000000u - 2048u)));
     if (ONLY) {  // the records that stay are known: ask for their places now, the answer is read after the rare paths
         n_rec = lm_count(m_valid & ~m_defer);
-        if (n_rec && !DIRECT) a_old = alloc_issue_e(bl.alloc_state, n_rec);
+        if (n_rec && !DIRECT && !STAGE) a_old = alloc_issue_e(bl.alloc_state, n_rec);
     }
     u32x4 rec;
     rec.x = lm_select(m_swap, bzp.w, azp.w); rec.y = lm_select(m_swap, azp.w, bzp.w);
@@ -426,6 +473,12 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
         rec.z = __float_as_uint((float)y);
         rec.w = kind;
         if (ONLY) { if (n_rec == 0u) return; }
+        if constexpr (STAGE) {  // the wave's own region: the next n_rec places, no allocator at all
+            if (__builtin_expect(sg.n + n_rec > kWaveStageRecords, 0)) stage_flush_g(sg, tg, result, lane);
+            lm_store_records_cached(m_valid, sg.buf, (sg.n + lm_rank(m_valid)) << 4, rec);
+            sg.n += n_rec;
+            return;
+        }
         // The allocator's common case, hand-scheduled (left to the compiler: ~25 scalar instructions of selects and flag words): the n records
         // fit the block's current chunk (used + n <= CHUNK) and the chunk lies wholly inside the first 2^32 bytes of the caller's buffer (chunk <
         // cap_chunks) -> one run, scalar base + the 32-bit byte offset (position + rank) * 16, stored under the valid mask as exec.
@@ -485,8 +538,22 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
             }
             if (n_rec == 0u) return;
         }
+        if (STAGE && m_defer) {  // launched on the engine's memo that this input defers nothing, and it does after all: the host repeats the call with the
+                                 // chunked sequence and its probe pass (status bit 128, as k_fixup raises it for a skipped pass); these records do not matter
+            if (lane == 0u) atomicOr(&result[1], 128ull);
+            if (ONLY) n_rec = lm_count(m_valid);
+            m_defer = 0ull;
+        }
         if (DIRECT) {
             if (sg.n + n_rec > kStageRecords) stage_flush_e(sg, tg, result, lane);
+            rec.w = kind;
+            if (lm_lane(m_valid, lane)) sg.buf[sg.n + lm_rank(m_valid)] = make_uint4(rec.x, rec.y, rec.z, rec.w);
+            sg.n += n_rec;
+            return;
+        }
+        if (STAGE) {
+            if (n_rec == 0u) return;
+            if (sg.n + n_rec > kWaveStageRecords) stage_flush_g(sg, tg, result, lane);
             rec.w = kind;
             if (lm_lane(m_valid, lane)) sg.buf[sg.n + lm_rank(m_valid)] = make_uint4(rec.x, rec.y, rec.z, rec.w);
             sg.n += n_rec;
@@ -518,9 +585,12 @@ DEVFN void exact_finish_e(const ExactRegs &g, const ConstsE &K, const TablesE &t
 // no holes and the launch sequence no fix-up kernel (stage_flush_e above; engine.cpp finish_result)
 struct StageLdsE { uint4 rec[4][kStageRecords]; uint32_t wave_n[4]; unsigned long long base; };
 struct NoStageLdsE { uint4 rec[1][1]; uint32_t wave_n[1]; unsigned long long base; };
+struct ScratchStageLdsE { uint4 rec[1][1]; uint32_t wave_n[kEWaves]; unsigned long long base; };  // STAGE: the records are in the scratch block, only the block-end sums here
 // RES: the residue rule is applied to every prefilter survivor before it is queued (compact_rounds_res_e) -- the launcher's choice for inputs whose
 // residues are runs of atoms; the result is the same list either way
-template <int WAVES, int SPLIT, bool ONLY, bool DIRECT = false, bool RES = false>
+// STAGE: the hole-free sequence of the 12-wave kernels with the four-way task split (stage_copy_g above): launched only when the engine's memo says the input
+// defers nothing to the probe pass
+template <int WAVES, int SPLIT, bool ONLY, bool DIRECT = false, bool RES = false, bool STAGE = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) void k_emit(DevAtoms in, const GridParams *gp, const DevParams *dprm, const uint32_t *cell_start, Sorted so,
                                                                                            EmitTarget tg, ulonglong2 *hole_list, uint32_t *task_ctr, unsigned long long *result) {
     // Inputs that do not fill the chip emit a few thousand records per block, or a few hundred: a 4096-record chunk per block would leave
@@ -529,13 +599,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     // The 4-wave kernels' inputs (DIRECT: below 320 tasks) go without chunks altogether: the records are staged per wave and flushed to places
     // taken from the global record counter (stage_flush_e): no holes, no fix-up launch.
     static_assert(!DIRECT || WAVES == 4, "the hole-free sequence is the 4-wave kernels'");
-    constexpr uint32_t kChunkE = DIRECT ? 1u : (SPLIT == 4 ? kSmallChunkRecords : kChunkRecords);
+    static_assert(!STAGE || (!DIRECT && SPLIT == 4), "the scratch-staged sequence is the 12-wave kernels' with the task split");
+    constexpr uint32_t kChunkE = DIRECT ? 1u : (STAGE ? 2u : (SPLIT == 4 ? kSmallChunkRecords : kChunkRecords));
     static_assert(DIRECT || WAVES == kEWaves, "the 4-wave kernels are DIRECT");
     static_assert(!(RES && DIRECT), "the residue-rule rounds are the 12-wave kernels'");
     __shared__ TablesE tb;
     __shared__ typename std::conditional<RES, WaveLdsR, WaveLdsN>::type wl[WAVES];
     __shared__ BlockLds bl;
-    __shared__ typename std::conditional<DIRECT, StageLdsE, NoStageLdsE>::type stg;
+    __shared__ typename std::conditional<DIRECT, StageLdsE, typename std::conditional<STAGE, ScratchStageLdsE, NoStageLdsE>::type>::type stg;
     // (the grid and parameter words first: their loads travel together with the table's instead of behind the barrier)
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
     const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
@@ -568,7 +639,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     WaveLdsE &w = wl[wave].e;
     uint32_t nkey_lds = 0;  // RES: LDS byte address of the staged chunk's residue words
     if constexpr (RES) nkey_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)wl[wave].nkey);
-    StageRef sg{stg.rec[DIRECT ? wave : 0u], 0u};
+    StageRef sg{STAGE ? reinterpret_cast<uint4 *>(tg.scratch) + (size_t)(blockIdx.x * (uint32_t)WAVES + wave) * kWaveStageRecords : stg.rec[DIRECT ? wave : 0u], 0u};
     const ProbeParamsE pe{dprm->s_clash, dprm->s_cov, tb.s_vdw, dprm->s_hacc, K.s_ion, K.s_polar, K.s_hphob};
     // task distribution as in k_pairs: block group (b mod 8) = one XCD = one contiguous eighth of the tasks, static first task per wave
     const uint32_t n_groups = min(8u, gridDim.x), group = blockIdx.x % n_groups;
@@ -734,7 +805,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
         t = g_lo + group_waves + __builtin_amdgcn_readfirstlane(nxt_task);
     }
     emit_epilogue(bl, hole_list + blockIdx.x, tg);
-    if (DIRECT) {  // what the waves still hold goes out together: one returning atomic per block
+    if (DIRECT || STAGE) {  // what the waves still hold goes out together: one returning atomic per block
         const uint32_t mine = __builtin_amdgcn_readfirstlane(sg.n);
         if (lane == 0u) stg.wave_n[wave] = mine;
         __syncthreads();
@@ -746,7 +817,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
         __syncthreads();
         unsigned long long pos = stg.base;
         for (uint32_t k = 0; k < wave; k++) pos += stg.wave_n[k];
-        stage_copy_e(sg.buf, mine, pos, tg, result, lane);
+        if (STAGE) stage_copy_g(sg.buf, mine, pos, tg, lane);
+        else stage_copy_e(sg.buf, mine, pos, tg, result, lane);
     }
 }
 
@@ -771,7 +843,17 @@ bool launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
                                                  (const uint32_t *)ws.cell_start, ws.sorted, tg, ws.hole_list, ws.task_ctr, ws.result)
     // res_filter: the residue-rule kernels (the engine asks for them when the input's residues are runs of atoms, and had k_place write the residue
     // words); the 4-wave kernels of the smallest inputs have no such variant (a call of that size is launches and round trips, not batches)
-    if (contacts_only) {
+    // stage: the hole-free sequence of the task-split 12-wave kernels (k_emit<.., STAGE>: records staged per wave in the scratch block, no fix-up launch) -- for
+    // inputs the engine's memo says defer nothing (skip_deferred: the kernel raises status bit 128 if they do after all and the host repeats the call with the
+    // chunked sequence), whose waves' regions fit the scratch block
+    // (up to kStageTasks tasks = 131 k atoms: every record crosses the L2 twice more on this route, which costs the kernel ~1 us per 3 x 10^5 records -- S2 per step,
+    // staged against chunks + fix-up: 3 x 10^4 atoms 53 against 64 us, 6 x 10^4 64 / 71, 10^5 76 / 82 (S1 65 / 80), 1.9 x 10^5 106 / 102, 2.9 x 10^5 146 / 129)
+    constexpr uint32_t kStageTasks = 2048;
+    const bool stage = shared && !narrow && tasks <= kStageTasks && !in.per_model && skip_deferred && (unsigned long long)nb * kEWaves * kWaveStageRecords <= ws.scratch_cap;
+    if (stage) {
+        if (contacts_only) { if (res_filter) ARP_LAUNCH_E(kEWaves, 4, true, false, true, true); else ARP_LAUNCH_E(kEWaves, 4, true, false, false, true); }
+        else { if (res_filter) ARP_LAUNCH_E(kEWaves, 4, false, false, true, true); else ARP_LAUNCH_E(kEWaves, 4, false, false, false, true); }
+    } else if (contacts_only) {
         if (eight) ARP_LAUNCH_E(4, 8, true, true);
         else if (narrow) ARP_LAUNCH_E(4, 4, true, true);
         else if (shared) { if (res_filter) ARP_LAUNCH_E(kEWaves, 4, true, false, true); else ARP_LAUNCH_E(kEWaves, 4, true); }
@@ -783,7 +865,7 @@ bool launch_emit_e(const DevAtoms &in, const Workspace &ws, arp_pair *out, unsig
         else { if (res_filter) ARP_LAUNCH_E(kEWaves, 1, false, false, true); else ARP_LAUNCH_E(kEWaves, 1, false); }
     }
 #undef ARP_LAUNCH_E
-    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, direct ? 1u : (shared ? kSmallChunkRecords : kChunkRecords));
-    return direct;
+    launch_emit_tail(in, ws, tg, nb, st, prof, skip_deferred, !contacts_only, (direct || stage) ? 1u : (shared ? kSmallChunkRecords : kChunkRecords));
+    return direct || stage;  // (the host derives the count and the capacity flag from result[2]: engine.cpp finish_result)
 }
 static_assert(kEBlocks + 384u <= kMaxHoles && 1536u + 384u <= kMaxHoles, "hole list: one entry per block of either kernel");

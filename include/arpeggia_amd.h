@@ -96,7 +96,8 @@ typedef struct arp_atoms {
 /* NO_SPECULATION (arp_contacts_atomic_enqueue): the single-pass emitter normally skips the launch of the probe pass (hydrogen-bond angles,
  * disulfide dihedrals) when the previous call on the same arrays needed none, checks the guess on the device, and lets
  * arp_contacts_atomic_result repeat the whole call when the guess was wrong -- until then the records a probe decides sit in `out` with
- * kind 0 (inputs below ~20 000 atoms run their probes inside the emitter: nothing is speculated there).  With this flag the probe pass is always launched behind the emitter, on the same stream: work the caller orders on that stream
+ * kind 0 (inputs below ~20 000 atoms run their probes inside the emitter: nothing is speculated there; between ~20 000 and ~131 000 atoms the same
+ * guess also selects a launch sequence without the hole fix-up -- if it was wrong nothing of that call's output is valid until the repeat has run).  With this flag the probe pass is always launched behind the emitter, on the same stream: work the caller orders on that stream
  * after the enqueue sees final records.  (One repeat remains possible, for either setting: a deferred-probe list that overflows -- an input
  * with more than ~16 probe candidates per atom -- is grown by arp_contacts_atomic_result and the call run again; it then returns only after
  * the repeat, and what ran on the stream in between has seen an incomplete list.  ARP_FLAG_DETERMINISTIC never speculates.) */

@@ -20,7 +20,8 @@ for f in sys.argv[1:]:
         if k in d:
             line("   " + k, d[k])
     if "files" in d:
-        print("    files", {n: (round(v["us_per_call_on_stream"], 1), round(v["get_contacts_warm_us"], 1), v["table_rows"]) for n, v in d["files"].items() if isinstance(v, dict)})
+        print("    files", {n: (round(v["us_per_call_on_stream"], 1), round(v["get_contacts_warm_us"], 1), round(v.get("get_contacts_c_abi_warm_us", 0.0), 1), v["table_rows"])
+                            for n, v in d["files"].items() if isinstance(v, dict)})
     if "sap" in d:
         print("    sap", {n: (round(v["sum_kernel_us"], 1), round(v["device_us_per_call"], 1)) for n, v in d["sap"].items() if isinstance(v, dict)})
     r = d["roofline"]

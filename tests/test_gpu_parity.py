@@ -788,14 +788,15 @@ def test_ordered_paths_on_a_fresh_context_and_after_a_workspace_regrow():
         assert_pairs_equal(c.atomic_contacts(big.view("/")), want_big, "single pass after regrow")
 
 
-def test_deferred_pass_memo_survives_new_content_in_the_same_buffers():
+@pytest.mark.parametrize("n_res", [300, 2600])  # (2600 residues with hydrogens: ~32 k atoms, the range of the scratch-staged hole-free sequence of round 5)
+def test_deferred_pass_memo_survives_new_content_in_the_same_buffers(n_res):
     """The engine skips the launch of the probe pass when the previous call on the same (x pointer, n) deferred nothing; the fix-up checks
     on the device that nothing was deferred THIS time and the host repeats the call with the pass otherwise.  Here the caller's device
     buffers keep their addresses while their CONTENT alternates between a cloud that defers nothing and a hydrogen-rich structure of the
     same size whose HydrogenBond / Disulfide kinds only the probe pass can decide -- every call must equal the oracle, whatever the memo
     guessed (enqueue/result and the one-call form; all candidates and contacts only)."""
     torch = pytest.importorskip("torch")
-    rec_b = synth.gen_stress(n_res=300, seed=17)
+    rec_b = synth.gen_stress(n_res=n_res, seed=17, box=28.0 * (n_res / 400.0) ** (1.0 / 3.0))
     prod_b = aa.Structure.from_records(rec_b)
     soa_b = prod_b.soa("/")
     n = len(soa_b["x"])
@@ -836,6 +837,45 @@ def test_deferred_pass_memo_survives_new_content_in_the_same_buffers():
             assert got_n == len(w), f"{name} only={only}: {got_n} pairs vs oracle {len(w)}"
             assert_pairs_equal(out[:got_n].cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1), w, f"memo {name} only={only} (enqueue)")
             assert_pairs_equal(c.atomic_contacts(atoms[name], prm), w, f"memo {name} only={only} (one call)")
+
+
+@pytest.mark.parametrize("gen,n", [("s2", 30000), ("s1", 30000), ("s2", 100000), ("s1", 100000), ("s1", 131000)])
+def test_staged_hole_free_sequence_on_resident_inputs(gen, n):
+    """Round 5: between 20 480 and ~131 k atoms a REPEATED call on the same device arrays (the engine's memo: the previous call deferred nothing) runs
+    k_emit<.., STAGE>: every wave stages its records in a region of its own in the scratch block, the block takes exact places at its end, and no
+    fix-up kernel runs.  First call (chunks + fix-up) and the staged calls after it must all equal the oracle: all candidates and contacts only, plain
+    and residue-rule kernels; a buffer that is too small must report the count it needs (the staged copy drops what does not fit, it never spills
+    into the scratch block that holds the other waves' regions) and a retry with enough room must be right."""
+    torch = pytest.importorskip("torch")
+    rec = getattr(synth, f"gen_{gen}")(n)
+    soa = aa.Structure.from_records(rec, hierarchy=True).soa("/")
+    want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True).atomic_contacts()
+    dev = {k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else v).cuda() for k, v in soa.items()}
+    keep = []
+    atoms = aa.atoms_from_arrays(dev, location=_lib.ARP_MEM_DEVICE, keep=keep)
+    c = aa.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    out = torch.empty((len(want) + 64, 4), dtype=torch.int32, device="cuda")
+    for only in (False, True):
+        w = want[want["kind"] != 0] if only else want
+        for runs in (False, True):
+            prm = aa.default_params(contacts_only=only, residue_runs=runs)
+            for call in range(3):
+                out.zero_()
+                c.enqueue(atoms, prm, out.data_ptr(), out.shape[0])
+                got_n = c.result()
+                assert got_n == len(w), f"{gen} {n} only={only} runs={runs} call {call}: {got_n} vs {len(w)}"
+                assert_pairs_equal(out[:got_n].cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1), w, f"{gen} {n} only={only} runs={runs} call {call}")
+            # too small a buffer on the staged route: the needed count comes back, nothing is written past the capacity
+            small = len(w) // 2
+            guard = out[small:small + 64].clone()
+            c.enqueue(atoms, prm, out.data_ptr(), small)
+            with pytest.raises(aa.ArpeggiaError) as e:
+                c.result()
+            assert e.value.status == _lib.ARP_ERR_CAPACITY and str(len(w)) in str(e.value)
+            assert torch.equal(out[small:small + 64], guard)
+            c.enqueue(atoms, prm, out.data_ptr(), out.shape[0])
+            assert c.result() == len(w)
+            assert_pairs_equal(out[:len(w)].cpu().numpy().view(aa.PAIR_DTYPE).reshape(-1), w, f"{gen} {n} only={only} runs={runs} after a capacity error")
 
 
 @pytest.mark.parametrize("n_res", [300, 1800])
