@@ -47,3 +47,17 @@ for n_ctx in (1, 2):
     dt, rec = run(n_ctx, True)
     aa.debug_set("timing", 0)
     print(f"     whole call {dt * 1e3:8.3f} ms, {rec} records", file=sys.stderr, flush=True)
+
+# The bench line's order of legs (fresh contexts): contacts only 1 ctx, all candidates 1 ctx, contacts only 2 ctx, all candidates 2 ctx -- every iteration printed,
+# the third 2-context contacts-only iteration with laps.
+print("---- bench order, fresh contexts ----", flush=True)
+c2, c3 = aa.Context(0), aa.Context(0)
+for name, only, n_ctx in (("contacts_only", True, 1), ("all_candidates", False, 1), ("contacts_only_2ctx", True, 2), ("all_candidates_2ctx", False, 2), ("contacts_only_2ctx again", True, 2)):
+    its = []
+    for k in range(3):
+        if name.startswith("contacts_only_2ctx") and k == 2:
+            print(f"---- laps: {name}, iteration 3 ----", file=sys.stderr, flush=True)
+            aa.debug_set("timing", 1)
+        its.append(run(n_ctx, only)[0])
+        aa.debug_set("timing", 0)
+    print(f"{name:26s}: " + "  ".join(f"{t * 1e3:7.3f} ms" for t in its) + f"   best {min(its) / n * 1e6:6.2f} us per structure", flush=True)

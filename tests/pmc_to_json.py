@@ -1,7 +1,7 @@
 """profiles/rNN_traffic.json from a PMC summary (tests/pmc_summary.py output): the HBM-side traffic and the instruction-issue figures of the
 dominant kernel, TAGGED WITH THE CONTENT HASH OF THE SOURCES the profiled library was built from (arpeggia_amd/build.py source_hash) --
 bench.py attaches the measurement to its `roofline` object only when that hash equals the running library's.
-Usage: python tests/pmc_to_json.py SUMMARY.txt OUT.json --workload s2 --atoms 1000000 --pairs 28702955 [--kernel 'arp::k_emit<12, 1, false, false, false>']"""
+Usage: python tests/pmc_to_json.py SUMMARY.txt OUT.json --workload s2 --atoms 1000000 --pairs 28702955 [--kernel 'arp::k_emit<12, 1, false, false' (a prefix)]"""
 import argparse
 import importlib.util
 import json
@@ -23,12 +23,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("summary"); ap.add_argument("out")
     ap.add_argument("--workload", default="s2"); ap.add_argument("--atoms", type=int, default=1_000_000); ap.add_argument("--pairs", type=int, required=True)
-    ap.add_argument("--kernel", default="arp::k_emit<12, 1, false, false, false>")
+    ap.add_argument("--kernel", default="arp::k_emit<12, 1, false, false")
     ap.add_argument("--source", default=None, help="path of the summary as committed under profiles/")
     a = ap.parse_args()
     txt = Path(a.summary).read_text()
-    i = txt.index(a.kernel + "\n")
-    block = txt[i + len(a.kernel) + 1:]
+    # (--kernel is a PREFIX of the summary's kernel line: the symbol grows a template argument now and then -- round 5 added two)
+    m0 = re.search(r"^" + re.escape(a.kernel) + r"[^\n]*\n", txt, re.M)
+    if not m0:
+        raise SystemExit(f"no kernel line starting with {a.kernel!r} in {a.summary}")
+    a.kernel = m0.group(0).strip()
+    block = txt[m0.end():]
     j = re.search(r"^\S", block, re.M)
     block = block[: j.start()] if j else block
     c = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+mean\s+([0-9.eE+-]+)", block, re.M)}

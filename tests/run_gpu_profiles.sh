@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 # The counter passes first: the bench line attaches `roofline.traffic` / `issue` only from a profile whose source hash is the running library's
 # (bench.py), so the profile of THIS build has to exist in profiles/ before the bench runs (the copy in the box's tree; it comes home via $OUT).
-bash tests/run_gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary.txt; grep -A30 "k_emit<12, 1, false, false, false>" $OUT/pmc_summary.txt | head -32
+bash tests/run_gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary.txt; grep -A30 "k_emit<12, 1, false, false" $OUT/pmc_summary.txt | head -32
 PAIRS=$(timeout -k 10 200 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --profile-steps 0 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['config']['pairs_per_gpu'])")
 python3 tests/pmc_to_json.py $OUT/pmc_summary.txt $OUT/traffic.json --pairs $PAIRS --source profiles/${TAG}_pmc_summary.txt && cp $OUT/traffic.json profiles/${TAG}_traffic.json
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -3 $OUT/bench.err; exit 1; }
