@@ -16,7 +16,7 @@ timeout -k 10 200 python tests/e2e_timing.py > $OUT/e2e.txt 2>&1; tail -12 $OUT/
 timeout -k 10 200 python tests/small_timing.py > $OUT/small.txt 2>&1; tail -6 $OUT/small.txt
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --profile-steps 0 > $OUT/stats.log 2>&1
-find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -12
+cp "$(ls -t $(find $OUT/stats -name "*kernel_stats.csv") | head -1)" $OUT/kernel_stats.csv; head -12 $OUT/kernel_stats.csv  # (gpurun merges earlier calls' trees into the local copy: take $OUT/kernel_stats.csv, not whatever find lists first)
 timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tests/batch_timing.py 2048 trace > $OUT/trace.log 2>&1
 python3 $GRAFT_REPO_ROOT/tests/trace_overlap.py $OUT/trace > $OUT/batch_overlap.txt 2>&1; cat $OUT/batch_overlap.txt
 rm -rf $OUT/trace/*/*kernel_trace.csv $OUT/trace/*/*memory_copy_trace.csv 2>/dev/null
