@@ -28,6 +28,8 @@ struct DevParams {
     uint32_t flags;       // arp_params.flags (ARP_FLAG_CONTACTS_ONLY is read by the pair kernels)
     double r2_call;       // dist_cutoff^2 (complex.rs:191) as the caller gave it.  Everything but r2, r2f and s_cov_max is constant for a given
                           // arp_params: the device copy is uploaded when the parameters change, not per call
+    uint32_t strip_force; // diagnostics (arp_debug_set "strip_rows"): rows per y strip of the cell order, a power of two; 0 = chosen by input size
+    uint32_t pad_;
 };
 
 // Uniform grid, written by the device-side setup kernel (no host round trip).
@@ -39,7 +41,7 @@ struct GridParams {
     uint32_t kx;          // x cells per cell edge (1, 2 or 4): a neighbour within the cutoff is at most kx cells away along x
     uint32_t nx, ny, nz;  // cells per axis for ONE model
     uint32_t nzt;         // total z layers = n_models * (nz + 1): each model gets its own slab + an empty separator
-    uint32_t ncells;      // nx * ny * nzt
+    uint32_t ncells;      // nx * ny * nzt (ny rounded up to whole strips when sy_shift != 0)
     uint32_t n_heavy;     // atoms in the grid (non-H)
     uint32_t n_tasks;     // ceil(n_heavy / 64): one wave-task per 64 consecutive slots
     uint32_t bad;         // bit 0: non-finite coordinate seen, bit 1: model ids too sparse for the workspace
@@ -51,8 +53,20 @@ struct GridParams {
                               // position, however far apart the members are in space; nullptr = one origin for all models
     uint32_t rk_bad;      // k_place met a residue ordinal or chain rank that does not fit the 32-bit residue word (Sorted::rkey): the residue-rule
                           // kernels (k_emit<.., RES>) then reject nothing early -- the exact phase decides on the real keys, as always
-    uint32_t pad_;
+    uint32_t sy_shift;    // cell rows run (layer, y) when 0; else in y strips of 2^sy_shift rows: (strip, layer, y inside the strip) -- grid_row
 };
+
+// Row of cells (y, layer) -> its place in the cell order; a row's nx cells are consecutive.  Layer-major order keeps a row's neighbours in the
+// next layer a whole layer of atoms away: the emit kernel's gathers find them in the XCD's 4 MB L2 only while two layers of records fit there
+// (up to ~2 x 10^6 atoms of a compact structure).  Beyond that the rows are ordered in y strips (grid_setup picks the height), and the distance
+// is a strip's share of a layer.  ny: the real row count (sy_shift == 0); strips pad it to a multiple of their height with empty rows.
+__host__ __device__ inline uint32_t grid_row(uint32_t y, uint32_t layer, uint32_t ny, uint32_t nzt, uint32_t s) {
+    return s ? ((((y >> s) * nzt + layer) << s) | (y & ((1u << s) - 1u))) : layer * ny + y;
+}
+__host__ __device__ inline void grid_row_decode(uint32_t r, uint32_t ny, uint32_t nzt, uint32_t s, uint32_t &y, uint32_t &layer) {
+    if (s) { const uint32_t q = r >> s; layer = q % nzt; y = ((q / nzt) << s) | (r & ((1u << s) - 1u)); }
+    else { y = r % ny; layer = r / ny; }
+}
 
 // Device view of the caller's SoA (all device pointers).
 struct DevAtoms {

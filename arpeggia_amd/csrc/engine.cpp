@@ -92,6 +92,7 @@ void make_dev_params(const arp_params &p, DevParams *d) {
     d->s_cov_max = 0.0;
     for (int k = 0; k < 256; k++) d->s_cov_max = std::max(d->s_cov_max, d->s_cov[k]);  // (s_cov >= s_clash after the clamp above)
     d->r2f = (float)d->r2;
+    d->strip_force = g_debug.strip_rows > 0 ? (uint32_t)g_debug.strip_rows : 0u;
     d->flags = p.flags;
 }
 
@@ -1240,7 +1241,7 @@ extern "C" int32_t arp_profile_read(arp_context *ctx, const char **names, float 
 }
 
 // ---- library-level -----------------------------------------------------------------------------------------------
-namespace arp { DebugKnobs g_debug{0, 0, 0, 0}; }
+namespace arp { DebugKnobs g_debug{0, 0, 0, 0, 0}; }
 extern "C" arp_status arp_debug_set(const char *key, int64_t value) {
     if (!key) { set_error("null key"); return ARP_ERR_BAD_INPUT; }
     const std::string k(key);
@@ -1248,7 +1249,11 @@ extern "C" arp_status arp_debug_set(const char *key, int64_t value) {
     else if (k == "emit_kernel") g_debug.emit_kernel = (int)value;
     else if (k == "defer_entries") g_debug.defer_entries = (long)value;
     else if (k == "table_host") g_debug.table_host = value != 0;
-    else { set_error("arp_debug_set: unknown key '%s' (timing, emit_kernel, defer_entries, table_host)", key); return ARP_ERR_BAD_INPUT; }
+    else if (k == "strip_rows") {
+        if (value < 0 || value > 1024 || (value & (value - 1)) != 0) { set_error("arp_debug_set: strip_rows takes 0 or a power of two up to 1024"); return ARP_ERR_BAD_INPUT; }
+        g_debug.strip_rows = (int)value;
+    }
+    else { set_error("arp_debug_set: unknown key '%s' (timing, emit_kernel, defer_entries, strip_rows, table_host)", key); return ARP_ERR_BAD_INPUT; }
     return ARP_OK;
 }
 extern "C" int32_t arp_api_version(void) { return ARP_API_VERSION; }

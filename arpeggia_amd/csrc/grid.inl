@@ -10,8 +10,9 @@
 
 // ---------------------------------------------------------------------------------------------- bounds + grid setup
 // (r2 = the call's squared search radius; returns the f32 prefilter threshold of the two-pass kernels, DevParams::r2f)
+constexpr uint32_t kStripLayerAtoms = 49152, kStripAtoms = 24576;  // strips above the first atoms per layer, sized for about the second per strip and layer
 DEVFN float grid_setup(const double lo_in[3], const double hi_in[3], bool empty, uint32_t n_models, uint32_t bad, GridParams *g, double r2,
-                       double cutoff, uint32_t ncells_cap, uint32_t n_atoms) {
+                       double cutoff, uint32_t ncells_cap, uint32_t n_atoms, uint32_t strip_force) {
     double lo[3], ext[3];
     for (int k = 0; k < 3; k++) {
         lo[k] = empty ? 0.0 : lo_in[k];
@@ -51,10 +52,20 @@ DEVFN float grid_setup(const double lo_in[3], const double hi_in[3], bool empty,
     g->kx = kx;
     g->nx = (uint32_t)nx; g->ny = (uint32_t)ny; g->nz = (uint32_t)nz;
     g->nzt = nm * (g->nz + 1u);
-    g->ncells = g->nx * g->ny * g->nzt;
+    // y strips (arp_internal.h grid_row): one model only -- a pack's members must stay contiguous in the cell order (batch.inl splits by slot range)
+    uint32_t sy = 0u;
+    if (nm == 1u && g->ny > 2u) {
+        const double layer_atoms = (double)n_atoms / nz;
+        double rows = strip_force ? (double)strip_force : (layer_atoms > (double)kStripLayerAtoms ? fmax(ny * (double)kStripAtoms / layer_atoms, 8.0) : 0.0);
+        while (rows >= 2.0 && (2u << sy) <= g->ny - 1u) { rows *= 0.5; sy++; }  // the largest power of two <= rows that leaves at least two strips
+        const unsigned long long padded = (unsigned long long)g->nx * (((g->ny + (1u << sy) - 1u) >> sy) << sy) * g->nzt;
+        if (padded > (unsigned long long)ncells_cap) sy = 0u;
+    }
+    g->sy_shift = sy;
+    g->ncells = g->nx * (sy ? (((g->ny + (1u << sy) - 1u) >> sy) << sy) : g->ny) * g->nzt;
     g->n_heavy = 0; g->n_tasks = 0;
     g->bad = bad;
-    g->rk_bad = 0u; g->pad_ = 0u;
+    g->rk_bad = 0u;
     // f32 prefilter: relative coordinates carry <= 2^-24 * extent of rounding each; a 10x-safe bound on the
     // induced error of dx^2+dy^2+dz^2 near the cutoff (derivation in DESIGN.md "Prefilter margin")
     const double M = fmax(ext[0], fmax(ext[1], ext[2])) + edge;
@@ -256,7 +267,7 @@ DEVFN void setup_block(BoxAcc &acc, SetupLds &l, bool publish, GridParams *g, De
     if (threadIdx.x == 0) {
         GridParams gl;
         const double zero[3] = {0.0, 0.0, 0.0};
-        const float r2f = grid_setup(model_box ? zero : acc.mn, model_box ? ext : acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, &gl, r2, cutoff, ncells_cap, n_atoms);
+        const float r2f = grid_setup(model_box ? zero : acc.mn, model_box ? ext : acc.mx, !(acc.mn[0] <= acc.mx[0]), acc.models, acc.bad & 0xFFu, &gl, r2, cutoff, ncells_cap, n_atoms, prm->strip_force);
         gl.model_org = model_box ? model_org : nullptr;
         gl.all_both = (acc.bad >> 24) & 1u ? 0u : 1u;
         l.g = gl;
@@ -289,7 +300,7 @@ DEVFN uint32_t cell_index(const GridParams &g, double x, double y, double z, uin
     cx = min(cx, g.nx - 1u); cy = min(cy, g.ny - 1u); cz = min(cz, g.nz - 1u);
     uint32_t layer = model * (g.nz + 1u) + cz;  // every model owns a z slab followed by one empty layer
     layer = min(layer, g.nzt - 1u);
-    return (layer * g.ny + cy) * g.nx + cx;
+    return grid_row(cy, layer, g.ny, g.nzt, g.sy_shift) * g.nx + cx;
 }
 
 // Cell of every atom and its arrival rank inside the cell.  A block takes 1024 consecutive atoms and merges those that fall into

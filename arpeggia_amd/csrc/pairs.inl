@@ -317,6 +317,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks;
+    const uint32_t sy = gp->sy_shift;
     const uint32_t wflags = (gp->all_both ? kWaveAllBoth : 0u) | ((dprm->flags & ARP_FLAG_CONTACTS_ONLY) ? kWaveContactsOnly : 0u);
     const double r2m = gp->r2m;
     WaveLds<MODE> &w = wl[wave];
@@ -347,20 +348,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
         if (have) {
             home = so.rec[a];
             uint32_t c = so.fat[a].cell;
-            cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
+            const uint32_t row = c / nx;
+            cx = c - row * nx; grid_row_decode(row, ny, nzt, sy, cy, cz);
         }
         const uint32_t xlo = cx > kx ? cx - kx : 0u, xhi = min(cx + kx, nx - 1);
         // all five slot windows of this lane up front: ten independent loads in flight instead of five round trips
         uint32_t wlo[5] = {0, 0, 0, 0, 0}, whi[5] = {0, 0, 0, 0, 0};
         if (have) {
-            wlo[0] = a + 1; whi[0] = cell_start[(cz * ny + cy) * nx + xhi + 1];
+            wlo[0] = a + 1; whi[0] = cell_start[grid_row(cy, cz, ny, nzt, sy) * nx + xhi + 1];
 #pragma unroll
             for (int k = 1; k < 5; k++) {
                 const int dy = (k == 1) ? 1 : (k - 3);
                 const uint32_t zz = cz + (k == 1 ? 0u : 1u);
                 const int yy = (int)cy + dy;
                 if (yy >= 0 && yy < (int)ny && zz < nzt) {
-                    const uint32_t r = (zz * ny + (uint32_t)yy) * nx;
+                    const uint32_t r = grid_row((uint32_t)yy, zz, ny, nzt, sy) * nx;
                     wlo[k] = cell_start[r + xlo]; whi[k] = cell_start[r + xhi + 1];
                 }
             }
@@ -383,7 +385,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, ((MODE == kEmit || MODE == kFi
                 const uint32_t ce = min(cs + kChunk, H);
                 const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
                 const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
-                if (!__any(len != 0u)) continue;
+                if (!__any(len != 0u)) {  // no lane's window reaches into this chunk: on to the first slot any lane still needs (lanes of one task can sit in
+                    // rows whose neighbour rows lie far apart in the cell order -- a whole y strip apart at a strip's edge, arp_internal.h grid_row)
+                    const uint32_t need = wave_min_u32((nonempty && hi > ce) ? max(lo, ce) : 0xFFFFFFFFu);
+                    if (need >= H) break;
+                    cs = need - kChunk;  // (>= cs: the chunk was a whole one, or no lane would be left; the loop's increment follows)
+                    continue;
+                }
                 wave_lds_fence();  // previous chunk fully consumed
                 for (uint32_t p = cs + lane; p < ce; p += 64u) w.nrec[p - cs] = so.rec[p];
                 wave_lds_fence();

@@ -609,6 +609,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
     __shared__ typename std::conditional<DIRECT, StageLdsE, typename std::conditional<STAGE, ScratchStageLdsE, NoStageLdsE>::type>::type stg;
     // (the grid and parameter words first: their loads travel together with the table's instead of behind the barrier)
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy, n_tasks = gp->n_tasks * (uint32_t)SPLIT;  // (wave-tasks)
+    const uint32_t sy = gp->sy_shift;  // (wave-uniform) the cell rows' order: arp_internal.h grid_row
     const uint32_t wflags = gp->all_both ? kWaveAllBoth : 0u;
     const uint32_t rk_off = RES ? gp->rk_bad : 0u;  // (wave-uniform) an ordinal or a chain rank did not fit the residue words: no early rejection
     const ConstsE K{dprm->r2, dprm->s_hphob, dprm->s_ion, dprm->s_polar, dprm->s_cov_max};
@@ -672,7 +673,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
                 hkey = ((unsigned long long)f.crm << 32) | f.res_ord;
                 if (RES && !rk_off) kh1 = ((f.crm & kRkChainMax) << kRkOrdBits) + (f.res_ord & ((1u << kRkOrdBits) - 1u)) - 1u;
                 const uint32_t c = f.cell;
-                cx = c % nx; cy = (c / nx) % ny; cz = c / (nx * ny);
+                const uint32_t row = c / nx;
+                cx = c - row * nx; grid_row_decode(row, ny, nzt, sy, cy, cz);
             }
             w.hxy[lane] = hxy; w.hzp[lane] = hzp; w.hkey[lane] = hkey;
         }
@@ -680,14 +682,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
         // all five slot windows of this lane up front: ten independent loads in flight instead of five round trips
         uint32_t wlo[5] = {0, 0, 0, 0, 0}, whi[5] = {0, 0, 0, 0, 0};
         if (have) {
-            wlo[0] = a + 1; whi[0] = cell_start[(cz * ny + cy) * nx + xhi + 1];
+            wlo[0] = a + 1; whi[0] = cell_start[grid_row(cy, cz, ny, nzt, sy) * nx + xhi + 1];
 #pragma unroll
             for (int k = 1; k < 5; k++) {
                 const int dy = (k == 1) ? 1 : (k - 3);
                 const uint32_t zz = cz + (k == 1 ? 0u : 1u);
                 const int yy = (int)cy + dy;
                 if (yy >= 0 && yy < (int)ny && zz < nzt) {
-                    const uint32_t r = (zz * ny + (uint32_t)yy) * nx;
+                    const uint32_t r = grid_row((uint32_t)yy, zz, ny, nzt, sy) * nx;
                     wlo[k] = cell_start[r + xlo]; whi[k] = cell_start[r + xhi + 1];
                 }
             }
@@ -712,7 +714,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == kEWaves ? kEWavesPerSimd : 2) 
                 const uint32_t ce = min(cs + kEChunk, Hw);
                 const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
                 const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
-                if (!__any(len != 0u)) continue;
+                if (!__any(len != 0u)) {  // no lane's window reaches into this chunk: on to the first slot any lane still needs (lanes of one task can sit in
+                    // rows whose neighbour rows lie far apart in the cell order -- a whole y strip apart at a strip's edge, arp_internal.h grid_row)
+                    const uint32_t need = wave_min_u32((nonempty && hi > ce) ? max(lo, ce) : 0xFFFFFFFFu);
+                    if (need >= Hw) break;
+                    cs = need - kEChunk;  // (>= cs: the chunk was a whole one, or no lane would be left; the loop's increment follows)
+                    continue;
+                }
                 wave_lds_fence();  // previous chunk fully consumed
                 // Staging: both halves of the chunk requested before either is waited for (one round trip per chunk, not two), from clamped
                 // addresses (the pad of a short chunk holds copies of its last record: never inside a lane's window).

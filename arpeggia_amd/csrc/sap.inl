@@ -30,6 +30,7 @@ __global__ __launch_bounds__(SPLIT * 64) void k_neighbor_sum(const GridParams *g
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     SapWaveLds &w = wl[wave];
     const uint32_t nx = gp->nx, ny = gp->ny, nzt = gp->nzt, kx = gp->kx, n_heavy = gp->n_heavy;
+    const uint32_t sy = gp->sy_shift;
     const uint32_t slot0 = blockIdx.x * 64u;
     if (slot0 >= n_heavy) return;  // (whole blocks only)
     const uint32_t a = slot0 + lane;
@@ -49,14 +50,16 @@ __global__ __launch_bounds__(SPLIT * 64) void k_neighbor_sum(const GridParams *g
         hx = h.x; hy = h.y; hz = h.z;
         const Fat &f = fat_at<false>(so.fat, a);
         ax = f.x; ay = f.y; az = f.z; orig = f.orig;
-        const uint32_t c = f.cell, cx = c % nx, cy = (c / nx) % ny, cz = c / (nx * ny);
+        const uint32_t c = f.cell, row = c / nx, cx = c - row * nx;
+        uint32_t cy, cz;
+        grid_row_decode(row, ny, nzt, sy, cy, cz);
         const uint32_t xlo = cx > kx ? cx - kx : 0u, xhi = min(cx + kx, nx - 1u);
 #pragma unroll
         for (uint32_t q = 0; q < kPer; q++) {  // all window bounds up front (independent loads)
             const uint32_t k = wave * kPer + q;
             const int zz = (int)cz + (int)(k / 3u) - 1, yy = (int)cy + (int)(k % 3u) - 1;
             if (zz >= 0 && zz < (int)nzt && yy >= 0 && yy < (int)ny) {
-                const uint32_t r = ((uint32_t)zz * ny + (uint32_t)yy) * nx;
+                const uint32_t r = grid_row((uint32_t)yy, (uint32_t)zz, ny, nzt, sy) * nx;
                 wlo[q] = cell_start[r + xlo]; whi[q] = cell_start[r + xhi + 1u];
             }
         }
@@ -74,7 +77,13 @@ __global__ __launch_bounds__(SPLIT * 64) void k_neighbor_sum(const GridParams *g
             const uint32_t ce = min(cs + kSapChunk, Hw);
             const uint32_t j0 = max(lo, cs), j1 = min(hi, ce);
             const uint32_t len = (nonempty && j1 > j0) ? j1 - j0 : 0u;
-            if (!__any(len != 0u)) continue;
+            if (!__any(len != 0u)) {  // no lane's window reaches into this chunk: on to the first slot any lane still needs (lanes of one task can sit in
+                // rows whose neighbour rows lie far apart in the cell order -- a whole y strip apart at a strip's edge, arp_internal.h grid_row)
+                const uint32_t need = wave_min_u32((nonempty && hi > ce) ? max(lo, ce) : 0xFFFFFFFFu);
+                if (need >= Hw) break;
+                cs = need - kSapChunk;  // (>= cs: the chunk was a whole one, or no lane would be left; the loop's increment follows)
+                continue;
+            }
             wave_lds_fence();  // previous chunk fully consumed
             {   // stage: {x, y, z, weight of the record's atom}; clamped addresses (the pad of a short chunk is never inside a window)
                 const uint32_t p0 = min(cs + lane, ce - 1u), p1 = min(cs + lane + 64u, ce - 1u);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void k_ring_atom(uint32_t n_rings, const RingEn
         if (model_serial_of[m] != ring.model_serial) continue;  // same serial = same model for the reference (complex.rs:96-98)
         for (uint32_t cz = lo[2]; cz <= hi[2]; cz++)
             for (uint32_t cy = lo[1]; cy <= hi[1]; cy++) {
-                const uint32_t row = ((m * (g.nz + 1u) + cz) * g.ny + cy) * g.nx;
+                const uint32_t row = grid_row(cy, m * (g.nz + 1u) + cz, g.ny, g.nzt, g.sy_shift) * g.nx;
                 const uint32_t s0 = cell_start[row + lo[0]], s1 = cell_start[row + hi[0] + 1u];
                 for (uint32_t p = s0 + threadIdx.x; p < s1; p += 64u) {
                     const Fat f = fat[p];

@@ -149,6 +149,8 @@ def measure_resident(aa, _lib, torch, dev, dev_index, soa, prm, steps, warmup, p
     keep = []
     atoms = aa.atoms_from_arrays(dsoa, location=_lib.ARP_MEM_DEVICE, keep=keep)
     stream = torch.cuda.current_stream(dev)
+    if os.environ.get("ARP_BENCH_STRIP_ROWS"):  # diagnostic: the cell rows in y strips of that many rows (arp_debug_set "strip_rows"; default: by input size)
+        aa.debug_set("strip_rows", int(os.environ["ARP_BENCH_STRIP_ROWS"]))
     ctx = aa.Context(dev_index, stream=stream.cuda_stream)
     n_pairs = ctx.count(atoms, prm)  # size the output once (count pass), then everything is allocation-free
     cap = max(n_pairs, 1) if check else n_pairs + n_pairs // 16 + 4096  # (diagnostic ablation builds, --no-check: their passes need not agree on the count)

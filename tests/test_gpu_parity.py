@@ -327,6 +327,44 @@ def test_residue_rule_kernels_emit_the_same_lists(ctx):
         assert_pairs_equal(fresh.atomic_contacts(soa), want, f"{what} memo call {k}")
 
 
+@pytest.mark.parametrize("rows", [2, 8, 32])
+def test_cell_rows_in_y_strips_emit_the_same_lists(rows):
+    """Round 5: above ~3 x 10^6 atoms the cell rows of a single-model input are ordered in y strips (arp_internal.h grid_row: the emit kernel's
+    gathers then find the next layer's rows in the L2).  arp_debug_set("strip_rows", N) forces strips of N rows on inputs of any size, so the order is
+    checked here against the oracle where the oracle finishes: every emit kernel family (hole-free 4-wave, 12-wave with and without the task
+    split, residue-rule, staged), the alternative single-pass kernel's twin k_pairs through the ordered two-pass emitter, hydrogens (deferred
+    probes address records by slot), the device table's ring-atom search (table_dev.hip walks the rows itself) and the SAP neighbour sum."""
+    aa.debug_set("strip_rows", rows)  # (for parameter blocks built from now on: the fresh context below)
+    try:
+        ctx = aa.Context(0)
+        for gen, n in (("gen_s2", 6000), ("gen_s1", 30000), ("gen_s2", 100000), ("gen_s1", 330000)):
+            rec = getattr(synth, gen)(n)
+            soa = aa.Structure.from_records(rec, hierarchy=True).soa("/")
+            want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True).atomic_contacts()
+            for k in range(2):  # (the second call: residue-rule kernels and the staged hole-free sequence, by the context's memos)
+                assert_pairs_equal(ctx.atomic_contacts(soa), want, f"{gen} {n} strips of {rows}, call {k}")
+            assert_pairs_equal(ctx.atomic_contacts(soa, aa.default_params(contacts_only=True)), want[want["kind"] != 0], f"{gen} {n} strips of {rows}, contacts only")
+            if n <= 30000:
+                got = ctx.atomic_contacts(soa, aa.default_params(deterministic=True))
+                assert_pairs_equal(got, want, f"{gen} {n} strips of {rows}, ordered")
+        rec = synth.gen_stress(n_res=2600, seed=5)
+        want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=False), flat=False).atomic_contacts()
+        assert_pairs_equal(ctx.atomic_contacts(aa.Structure.from_records(rec).soa("/")), want, f"hydrogen-rich, strips of {rows}")
+        for name, n_rows in (("1ubq", 532), ("6bft", 7236)):
+            table = ctx.get_contacts(aa.load_model(str(synth.DATA / f"{name}.pdb")), "/", 0.1, 6.5)
+            assert len(table["model"]) == n_rows
+            _lines_close(_table_lines(table), (GOLDEN / f"{name}_contacts.csv").read_text().splitlines()[1:])
+        rec = synth.gen_s1(40000)
+        rng = np.random.default_rng(3)
+        side = ~np.isin(rec["name"], [b"N", b"CA", b"C", b"O", b"OXT"])
+        w = rng.uniform(0.0, 1.0, len(side)).astype(np.float32)
+        got = aa.sap_neighbor_sum(ctx, rec["x"], rec["y"], rec["z"], side, w, 5.0)
+        want_sap = ob.sap_neighbor_sum(rec["x"], rec["y"], rec["z"], side, w, 5.0)
+        assert np.abs(got - want_sap).max() <= 2e-5 * max(1.0, float(np.abs(want_sap).max()))
+    finally:
+        aa.debug_set("strip_rows", 0)
+
+
 # ---------------------------------------------------------------------------------------------- edge cases
 def _mini(xyz, names=None, resn=None, elems=None, chains=None, resi=None):
     n = len(xyz)
