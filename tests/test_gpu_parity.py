@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): bit-exact contact-pair indices and interaction-t
 Run with `pytest -m gpu` on an MI355X box.  Reference citations are to y1zhou/arpeggia v0.8.0.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -362,7 +363,7 @@ def test_cell_rows_in_y_strips_emit_the_same_lists(rows):
         want_sap = ob.sap_neighbor_sum(rec["x"], rec["y"], rec["z"], side, w, 5.0)
         assert np.abs(got - want_sap).max() <= 2e-5 * max(1.0, float(np.abs(want_sap).max()))
     finally:
-        aa.debug_set("strip_rows", 0)
+        aa.debug_set("strip_rows", int(os.environ.get("ARP_TEST_STRIP_ROWS", "0")))  # (conftest.py: the whole suite may be running on strips)
 
 
 # ---------------------------------------------------------------------------------------------- edge cases
