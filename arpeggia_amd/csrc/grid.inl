@@ -10,7 +10,11 @@
 
 // ---------------------------------------------------------------------------------------------- bounds + grid setup
 // (r2 = the call's squared search radius; returns the f32 prefilter threshold of the two-pass kernels, DevParams::r2f)
-constexpr uint32_t kStripLayerAtoms = 49152, kStripAtoms = 24576;  // strips above the first atoms per layer, sized for about the second per strip and layer
+// y strips (arp_internal.h grid_row) once a layer of cells holds more than kStripLayerAtoms atoms, the largest power of two of rows that keeps a strip's share of
+// a layer at or below kStripAtoms.  Measured on one box, strips of 16 rows against layer order (tests/microbench/ab_r5m.sh; S2, emit us): 2 x 10^6 atoms
+// (30 k per layer) 296 / 297, 3 x 10^6 (40 k) 504 / 470, 4 x 10^6 (49 k) 687 / 633, 6 x 10^6 (64 k) 1083 / 945, 8 x 10^6 (77 k) 1466 / 1273; strips of 8 and 32
+// rows are both slower than 16 at 4 and 8 x 10^6 (ab_r5k.sh): 16 rows there are 9 500 / 12 000 atoms per strip and layer.
+constexpr uint32_t kStripLayerAtoms = 36864, kStripAtoms = 12288;
 DEVFN float grid_setup(const double lo_in[3], const double hi_in[3], bool empty, uint32_t n_models, uint32_t bad, GridParams *g, double r2,
                        double cutoff, uint32_t ncells_cap, uint32_t n_atoms, uint32_t strip_force) {
     double lo[3], ext[3];

@@ -149,7 +149,7 @@ typedef struct arp_table arp_table;         /* the 20-column contact table (mod.
  *                      the parity suite can check it on ordinary inputs; 0 (default): chosen by input size
  *   "defer_entries" N > 0: entries of the deferred-probe list of workspaces allocated from now on (a tiny list makes the grow-and-repeat path run)
  *   "strip_rows"    N = a power of two: the cell rows of single-model inputs are ordered in y strips of N rows (chosen by input size when 0, the default:
- *                      strips only above ~3 x 10^6 atoms), for parameter blocks built from now on -- lets the parity suite run the strip order on small inputs
+ *                      strips only from ~2.5 x 10^6 atoms of a compact structure on), for parameter blocks built from now on -- lets the parity suite run the strip order on small inputs
  *   "table_host"    1: only in the test library built with -DARP_WITH_HOST_TABLE (tests/hosttable): arp_get_contacts assembles the table on the host
  * Unknown keys return ARP_ERR_BAD_INPUT. */
 arp_status arp_debug_set(const char *key, int64_t value);

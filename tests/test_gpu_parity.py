@@ -492,6 +492,33 @@ def test_full_size_properties_1e6(ctx):
     assert_pairs_equal(a, orc.atomic_contacts(), "s2 1e6")
 
 
+def test_automatic_y_strips_at_full_size_match_the_oracle():
+    """A size at which grid_setup switches the cell rows to y strips BY ITSELF (grid.inl: more than 36 864 atoms per layer of a single-model
+    input): 3.3 x 10^6 S2 atoms -> ~9.4 x 10^7 records, against the oracle's list through the record count and the order-independent 64-bit hash
+    the bench line uses (bench.record_hash_numpy: sorting 10^8 records twice would take minutes), and against the same call in layer order
+    (strip_rows = 1) -- which must emit the same set."""
+    import bench
+
+    n = 3_300_000
+    rec = synth.gen_s2(n)
+    ext = [float(rec[k].max() - rec[k].min()) for k in ("x", "y", "z")]
+    nz = int(ext[2] / (6.5 * (1.0 + 1e-6))) + 1
+    assert n / nz > 36864, "this input no longer selects the strips: grid.inl kStripLayerAtoms"
+    soa = aa.Structure.from_records(rec, hierarchy=True).soa("/")
+    got = aa.Context(0).atomic_contacts(soa)
+    h_got = bench.record_hash_numpy(got["i"], got["j"], got["dist"], got["kind"])
+    want = ob.Structure.from_atoms(synth.records_to_oracle(rec, flat=True), flat=True).atomic_contacts()
+    assert len(got) == len(want) > 25 * n
+    assert h_got == bench.record_hash_numpy(want["i"], want["j"], want["dist"].astype(np.float32), want["kind"])
+    del want
+    aa.debug_set("strip_rows", 1)
+    try:
+        flat = aa.Context(0).atomic_contacts(soa)
+    finally:
+        aa.debug_set("strip_rows", int(os.environ.get("ARP_TEST_STRIP_ROWS", "0")))
+    assert len(flat) == len(got) and bench.record_hash_numpy(flat["i"], flat["j"], flat["dist"], flat["kind"]) == h_got
+
+
 def test_s1_cloud_1e6_vs_oracle(ctx):
     """The other half of BASELINE config 4 ("the headline run reports both"): the chemistry-faithful S1 cloud at 10^6 atoms, every pair against
     the oracle -- indices and flags bit-exact, f32 distances bit-identical -- for both emitters and for the contacts-only filter."""
