@@ -21,7 +21,7 @@ GOLDEN = ROOT / "tests" / "golden"
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # ARP_TEST_STRIP_ROWS=N: the whole suite on cell rows ordered in y strips of N rows (arp_debug_set "strip_rows"; by default only inputs above
-    # ~3 x 10^6 atoms are) -- a soak of the strip order on every input the suite has.  Tests that set the switch themselves restore it.
+    # ~2.5 x 10^6 atoms are) -- a soak of the strip order on every input the suite has.  Tests that set the switch themselves restore it.
     import os
 
     if os.environ.get("ARP_TEST_STRIP_ROWS"):

@@ -330,7 +330,7 @@ def test_residue_rule_kernels_emit_the_same_lists(ctx):
 
 @pytest.mark.parametrize("rows", [2, 8, 32])
 def test_cell_rows_in_y_strips_emit_the_same_lists(rows):
-    """Round 5: above ~3 x 10^6 atoms the cell rows of a single-model input are ordered in y strips (arp_internal.h grid_row: the emit kernel's
+    """Round 5: above ~2.5 x 10^6 atoms the cell rows of a single-model input are ordered in y strips (arp_internal.h grid_row: the emit kernel's
     gathers then find the next layer's rows in the L2).  arp_debug_set("strip_rows", N) forces strips of N rows on inputs of any size, so the order is
     checked here against the oracle where the oracle finishes: every emit kernel family (hole-free 4-wave, 12-wave with and without the task
     split, residue-rule, staged), the alternative single-pass kernel's twin k_pairs through the ordered two-pass emitter, hydrogens (deferred
