@@ -1,5 +1,6 @@
 """Parity of ONE emit kernel variant against the oracle, in a process of its own (arp_debug_set("emit_kernel", ...) is process-wide).
-Run by tests/test_gpu_parity.py::test_alternative_emit_kernels; usage: python tests/emit_kernel_check.py gather"""
+Run by tests/test_gpu_parity.py::test_alternative_emit_kernels; usage: python tests/emit_kernel_check.py gather
+(ARP_TEST_STRIP_ROWS=N in the environment: on cell rows forced into y strips of N rows)"""
 import sys
 from pathlib import Path
 
@@ -27,6 +28,10 @@ def check(ctx, prod, orc, what, **kw):
 
 
 def main():
+    import os
+
+    if os.environ.get("ARP_TEST_STRIP_ROWS"):  # (tests/conftest.py: the suite on forced y strips -- this process has to be told itself)
+        aa.debug_set("strip_rows", int(os.environ["ARP_TEST_STRIP_ROWS"]))
     aa.debug_set("emit_kernel", {"default": 0, "gather": 1}[sys.argv[1] if len(sys.argv) > 1 else "gather"])
     ctx = aa.Context(0)
     for name in ("1ubq", "6bft"):

@@ -362,6 +362,13 @@ def test_cell_rows_in_y_strips_emit_the_same_lists(rows):
         got = aa.sap_neighbor_sum(ctx, rec["x"], rec["y"], rec["z"], side, w, 5.0)
         want_sap = ob.sap_neighbor_sum(rec["x"], rec["y"], rec["z"], side, w, 5.0)
         assert np.abs(got - want_sap).max() <= 2e-5 * max(1.0, float(np.abs(want_sap).max()))
+        if rows == 8:  # the alternative single-pass kernel (k_pairs<kEmit>, the route of inputs beyond 2^24 slots) on strips, in a process of its own
+            import subprocess
+            import sys
+
+            r = subprocess.run([sys.executable, str(synth.DATA.parent / "emit_kernel_check.py"), "gather"], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, ARP_TEST_STRIP_ROWS="8"))
+            assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
     finally:
         aa.debug_set("strip_rows", int(os.environ.get("ARP_TEST_STRIP_ROWS", "0")))  # (conftest.py: the whole suite may be running on strips)
 
